@@ -1,0 +1,116 @@
+"""ctypes binding of libd3f_hip.so (include/d3f_hip.h).
+
+The library is the product path: there is no CPU / eager fallback.  If it cannot be loaded
+the import of any op raises, loudly.
+"""
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libd3f_hip.so"
+HEADER_PATH = _HERE.parent / "include" / "d3f_hip.h"
+
+F32, BF16 = 0, 1
+
+
+class D3FError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "H", "W", "C0", "C1", "upsample0", "Cout", "KH", "KW", "stride", "pad", "CinReal")]
+
+
+_p, _i, _i64, _f, _sz, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
+_desc = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol include/d3f_hip.h declares
+PROTOTYPES = {
+    "d3f_version": (_i, []),
+    "d3f_last_error": (C.c_char_p, []),
+    "d3f_unet_create": (_i, [C.c_char_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p)]),
+    "d3f_unet_destroy": (_i, [_p]),
+    "d3f_unet_num_params": (_i, [_p]),
+    "d3f_unet_param_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(C.c_int32), C.POINTER(_i), C.POINTER(_i64)]),
+    "d3f_unet_param_floats": (_i64, [_p]),
+    "d3f_unet_num_bn": (_i, [_p]),
+    "d3f_unet_bn_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i64)]),
+    "d3f_unet_bnstat_floats": (_i64, [_p]),
+    "d3f_unet_workspace_bytes": (_sz, [_p]),
+    "d3f_unet_forward_flops": (_dbl, [_p]),
+    "d3f_unet_backward_flops": (_dbl, [_p]),
+    "d3f_unet_pack_weights": (_i, [_p, _p, _p, _p]),
+    "d3f_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    "d3f_unet_num_segments": (_i, [_p]),
+    "d3f_unet_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "d3f_unet_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
+    "d3f_conv_packed_bytes": (_sz, [_i, _desc, _i]),
+    "d3f_conv_pack_weights": (_i, [_i, _desc, _p, _p, _p, _p]),
+    "d3f_conv_stats_floats": (_sz, [_i, _desc, C.POINTER(_i)]),
+    "d3f_conv_forward": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p]),
+    "d3f_conv_backward_data": (_i, [_i, _desc, _p, _p, _p, _p, _i, _i, _p]),
+    "d3f_conv_backward_weight_workspace_bytes": (_sz, [_i, _desc]),
+    "d3f_conv_backward_weight": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p]),
+    "d3f_bn_finalize": (_i, [_p, _i, _i, _i64, _p, _p, _p, _p, _p, _p]),
+    "d3f_bn_apply": (_i, [_i, _p, _p, _i, _i64, _p, _i, _p, _p]),
+    "d3f_bn_backward_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "d3f_bn_backward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _p, _p, _p]),
+    "d3f_maxpool3x3s2_forward": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "d3f_maxpool3x3s2_backward": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "d3f_upsample2x_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "d3f_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "d3f_nhwc_to_nchw": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "d3f_noise_blend": (_i, [_p, _p, _p, _f, _p, _p, _i, _i64, _p]),
+    "d3f_mse_ssim_loss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "d3f_mse_ssim_loss": (_i, [_p, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "d3f_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p]),
+    "d3f_ema_lerp": (_i, [_p, _p, _i64, _f, _p]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/d3f_hip.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(d3f_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises D3FError if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise D3FError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {LIB_PATH.parent}` (hipcc, gfx950). There is no CPU fallback.")
+    handle = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise D3FError(lib().d3f_last_error().decode("utf-8", "replace"))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

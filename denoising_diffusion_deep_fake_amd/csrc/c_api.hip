@@ -1,0 +1,311 @@
+// extern "C" surface of libd3f_hip.so: see include/d3f_hip.h for the contract.
+#include "../../include/d3f_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+namespace d3f {
+static thread_local char g_err[1024] = "";
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace d3f
+
+using namespace d3f;
+
+struct d3f_unet {
+  UnetEngine e;
+};
+
+static int desc_check(int dtype, const d3f_conv_desc* d) {
+  D3F_CHECK(d != nullptr, "conv: null descriptor");
+  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "conv: dtype %d", dtype);
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(d->B >= 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: extent");
+  D3F_CHECK(d->C0 % ve == 0 && d->C1 % ve == 0, "conv: channels must be multiples of %d", ve);
+  D3F_CHECK(d->KH == d->KW && d->KH >= 1 && d->KH <= 7, "conv: kernel %dx%d", d->KH, d->KW);
+  D3F_CHECK(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
+  D3F_CHECK(!d->upsample0 || (d->H % 2 == 0 && d->W % 2 == 0), "conv: up-sampled extent must be even");
+  D3F_CHECK(d->CinReal > 0 && d->CinReal <= d->C0 + d->C1, "conv: CinReal");
+  return 0;
+}
+
+struct Geo {
+  int Cin, Ho, Wo, CoutPad, Kpad, CoutD, KpadD, CinRows;
+};
+static Geo geo(int dtype, const d3f_conv_desc* d) {
+  const int ve = dtype == D3F_F32 ? 4 : 8, bke = dtype == D3F_F32 ? 32 : 64;
+  Geo g;
+  g.Cin = d->C0 + d->C1;
+  g.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  g.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  g.CoutPad = (int)round_up(d->Cout, 16);
+  g.Kpad = (int)round_up((long)d->KH * d->KW * g.Cin, bke);
+  g.CoutD = (int)round_up(d->Cout, ve);
+  g.KpadD = (int)round_up((long)d->KH * d->KW * g.CoutD, bke);
+  g.CinRows = (int)round_up(g.Cin, 16);
+  return g;
+}
+
+static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p) {
+  if (int rc = desc_check(dtype, d)) return rc;
+  const Geo g = geo(dtype, d);
+  std::memset(&p, 0, sizeof(p));
+  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = d->C0; p.C1 = d->C1;
+  p.shift0 = d->upsample0 ? 1 : 0;
+  p.H0s = d->H >> p.shift0; p.W0s = d->W >> p.shift0;
+  p.Ho = g.Ho; p.Wo = g.Wo; p.Cout = d->Cout; p.CoutPad = g.CoutPad; p.Kpad = g.Kpad;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.M = d->B * g.Ho * g.Wo;
+  return conv_igemm_plan(p, dtype);
+}
+
+extern "C" {
+
+int d3f_version(void) { return 100; }
+const char* d3f_last_error(void) { return g_err; }
+
+// ---- whole network ------------------------------------------------------------------------
+int d3f_unet_create(const char* encoder_name, int in_channels, int classes, int B, int H, int W,
+                    int dtype, d3f_unet_t* out) {
+  D3F_CHECK(out != nullptr && encoder_name != nullptr, "unet_create: null argument");
+  d3f_unet* h = new (std::nothrow) d3f_unet();
+  D3F_CHECK(h != nullptr, "unet_create: out of host memory");
+  const int rc = h->e.build(encoder_name, in_channels, classes, B, H, W, dtype);
+  if (rc != 0) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+int d3f_unet_destroy(d3f_unet_t h) {
+  delete h;
+  return 0;
+}
+int d3f_unet_num_params(d3f_unet_t h) { return h ? (int)h->e.params.size() : -1; }
+int d3f_unet_param_info(d3f_unet_t h, int i, char* name, int name_cap, int32_t shape[4], int* ndim,
+                        int64_t* offset) {
+  D3F_CHECK(h && i >= 0 && i < (int)h->e.params.size(), "param_info: index %d", i);
+  const ParamInfo& p = h->e.params[i];
+  if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", p.name.c_str());
+  for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+  *ndim = p.ndim;
+  *offset = p.offset;
+  return 0;
+}
+int64_t d3f_unet_param_floats(d3f_unet_t h) { return h ? h->e.param_floats : -1; }
+int d3f_unet_num_bn(d3f_unet_t h) { return h ? (int)h->e.bns.size() : -1; }
+int d3f_unet_bn_info(d3f_unet_t h, int i, char* prefix, int prefix_cap, int* C, int64_t* rm_offset,
+                     int64_t* rv_offset) {
+  D3F_CHECK(h && i >= 0 && i < (int)h->e.bns.size(), "bn_info: index %d", i);
+  const BnInfo& b = h->e.bns[i];
+  if (prefix && prefix_cap > 0) snprintf(prefix, (size_t)prefix_cap, "%s", b.prefix.c_str());
+  *C = b.C;
+  *rm_offset = b.rm_off;
+  *rv_offset = b.rv_off;
+  return 0;
+}
+int64_t d3f_unet_bnstat_floats(d3f_unet_t h) { return h ? h->e.bnstat_floats : -1; }
+size_t d3f_unet_workspace_bytes(d3f_unet_t h) { return h ? h->e.workspace_bytes : 0; }
+double d3f_unet_forward_flops(d3f_unet_t h) { return h ? h->e.fwd_flops : 0.0; }
+double d3f_unet_backward_flops(d3f_unet_t h) { return h ? h->e.bwd_flops : 0.0; }
+
+int d3f_unet_pack_weights(d3f_unet_t h, const float* params, void* workspace, void* stream) {
+  D3F_CHECK(h && params && workspace, "pack_weights: null argument");
+  return h->e.pack_weights(params, workspace, (hipStream_t)stream);
+}
+int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
+                     void* workspace, int training, void* stream) {
+  D3F_CHECK(h && params && bnstats && x && out && workspace, "unet_forward: null argument");
+  return h->e.forward(params, bnstats, x, out, workspace, training, (hipStream_t)stream);
+}
+int d3f_unet_num_segments(d3f_unet_t h) { return h ? h->e.num_segments : -1; }
+int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end) {
+  D3F_CHECK(h && segment >= 0 && segment < h->e.num_segments, "segment_range: segment %d", segment);
+  *begin = h->e.seg_grad_begin[segment];
+  *end = h->e.seg_grad_end[segment];
+  return 0;
+}
+int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
+                      void* workspace, int seg_begin, int seg_end, void* stream) {
+  D3F_CHECK(h && params && grad_out && grads && workspace, "unet_backward: null argument");
+  D3F_CHECK(seg_begin >= 0 && seg_end <= h->e.num_segments && seg_begin <= seg_end,
+            "unet_backward: segments [%d,%d)", seg_begin, seg_end);
+  return h->e.backward(params, grad_out, grads, workspace, seg_begin, seg_end, (hipStream_t)stream);
+}
+int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream) {
+  D3F_CHECK(h && name && workspace && out_nchw, "unet_export: null argument");
+  return h->e.export_tensor(name, workspace, out_nchw, (hipStream_t)stream);
+}
+
+// ---- single operators -----------------------------------------------------------------------
+size_t d3f_conv_packed_bytes(int dtype, const d3f_conv_desc* d, int which) {
+  if (desc_check(dtype, d) != 0) return 0;
+  const Geo g = geo(dtype, d);
+  const size_t es = dtype == D3F_F32 ? 4 : 2;
+  return which == 0 ? (size_t)g.CoutPad * g.Kpad * es : (size_t)g.CinRows * g.KpadD * es;
+}
+int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
+                          void* stream) {
+  if (int rc = desc_check(dtype, d)) return rc;
+  const Geo g = geo(dtype, d);
+  return pack_weights_launch(dtype, w, d->Cout, d->CinReal, g.Cin, d->KH, d->KW, w_fwd, g.CoutPad, g.Kpad,
+                             w_dgrad, g.CinRows, g.KpadD, (hipStream_t)stream);
+}
+size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int* tiles) {
+  ConvParams p;
+  if (fwd_params(dtype, d, p) != 0) return 0;
+  if (tiles) *tiles = p.tiles_m;
+  return (size_t)p.tiles_m * p.CoutPad * 2;
+}
+int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
+                     const void* w_fwd, void* y, float* stats, void* stream) {
+  ConvParams p;
+  if (int rc = fwd_params(dtype, d, p)) return rc;
+  D3F_CHECK(src0 && w_fwd && y && (d->C1 == 0 || src1), "conv_forward: null argument");
+  p.src0 = src0; p.src1 = src1; p.w = w_fwd; p.out0 = y; p.stats = stats; p.mode = CONV_RAW_STATS;
+  return conv_igemm_launch(p, dtype, (hipStream_t)stream);
+}
+int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
+                           void* dx0, void* dx1, int acc0, int acc1, void* stream) {
+  if (int rc = desc_check(dtype, d)) return rc;
+  const Geo g = geo(dtype, d);
+  D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
+  const int s2 = d->stride == 2;
+  D3F_CHECK(s2 ? (g.Ho * 2 == d->H && g.Wo * 2 == d->W) : (g.Ho == d->H && g.Wo == d->W),
+            "conv_backward_data: needs a 'same' (stride 1) or exactly halving (stride 2) conv");
+  D3F_CHECK(d->Cout % (dtype == D3F_F32 ? 4 : 8) == 0 || true, "unreachable");
+  ConvParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = g.CoutD; p.C1 = 0;
+  p.H0s = g.Ho; p.W0s = g.Wo; p.shift0 = s2; p.zi = s2;
+  p.Ho = d->H; p.Wo = d->W; p.Cout = g.Cin; p.CoutPad = g.CinRows; p.Kpad = g.KpadD;
+  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
+  p.M = d->B * d->H * d->W;
+  p.mode = CONV_DGRAD;
+  p.out_c0 = d->C1 > 0 ? d->C0 : g.Cin;
+  if (int rc = conv_igemm_plan(p, dtype)) return rc;
+  p.src0 = dy; p.w = w_dgrad; p.out0 = dx0; p.out1 = dx1; p.acc0 = acc0; p.acc1 = acc1;
+  return conv_igemm_launch(p, dtype, (hipStream_t)stream);
+}
+static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {
+  if (int rc = desc_check(dtype, d)) return rc;
+  const Geo g = geo(dtype, d);
+  std::memset(&w, 0, sizeof(w));
+  w.B = d->B; w.Hv = d->H; w.Wv = d->W; w.C0 = d->C0; w.C1 = d->C1;
+  w.shift0 = d->upsample0 ? 1 : 0;
+  w.H0s = d->H >> w.shift0; w.W0s = d->W >> w.shift0;
+  w.Ho = g.Ho; w.Wo = g.Wo; w.Cout = g.CoutD;
+  w.KH = d->KH; w.KW = d->KW; w.stride = d->stride; w.pad = d->pad;
+  w.M = d->B * g.Ho * g.Wo;
+  return wgrad_plan(w, dtype);
+}
+size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d) {
+  WgradParams w;
+  if (wgrad_params(dtype, d, w) != 0) return 0;
+  return wgrad_partial_floats(w) * sizeof(float);
+}
+int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, const void* src0,
+                             const void* src1, void* workspace, float* dw, void* stream) {
+  WgradParams w;
+  if (int rc = wgrad_params(dtype, d, w)) return rc;
+  D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
+  w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
+  if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
+  return wgrad_reduce_launch(w.partial, w.splits, w.Cout, d->Cout, d->C0 + d->C1, d->CinReal, d->KH, d->KW,
+                             dw, 0, (hipStream_t)stream);
+}
+
+int d3f_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float* coef, void* stream) {
+  D3F_CHECK(stats && gamma && beta && coef && C > 0 && tiles > 0 && count > 0, "bn_finalize: argument");
+  return bn_finalize_launch(stats, tiles, C, (int)round_up(C, 16), (long)count, gamma, beta, 1e-5f, 0.1f,
+                            running_mean, running_var, coef, coef + C, coef + 2 * C, coef + 3 * C,
+                            (hipStream_t)stream);
+}
+int d3f_bn_apply(int dtype, const void* y, const float* coef, int C, int64_t rows, const void* residual,
+                 int relu, void* out, void* stream) {
+  D3F_CHECK(y && coef && out, "bn_apply: null argument");
+  return bn_apply_launch(dtype, y, coef + 2 * C, coef + 3 * C, residual, nullptr, nullptr, nullptr, relu,
+                         out, (long)rows, C, (hipStream_t)stream);
+}
+size_t d3f_bn_backward_workspace_bytes(int dtype, int C, int64_t rows) {
+  return ((size_t)bn_bwd_reduce_blocks((long)rows, C, dtype) * C * 2 + 3 * (size_t)C) * sizeof(float) + 256;
+}
+int d3f_bn_backward(int dtype, const void* dA, const void* a_or_null, const void* y, const float* coef,
+                    const float* gamma, int C, int64_t rows, void* dy, void* dres, float* dgamma,
+                    float* dbeta, void* workspace, void* stream) {
+  D3F_CHECK(dA && y && coef && gamma && dy && dgamma && dbeta && workspace, "bn_backward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = reinterpret_cast<float*>(workspace);
+  const int blocks = bn_bwd_reduce_blocks((long)rows, C, dtype);
+  float* k = part + (size_t)round_up((long)blocks * C * 2, 4);
+  int nb = 0;
+  if (int rc = bn_bwd_reduce_launch(dtype, dA, a_or_null, y, coef, coef + C, part, &nb, (long)rows, C, s))
+    return rc;
+  if (int rc = bn_bwd_finalize_launch(part, nb, C, (long)rows, gamma, coef + C, dgamma, dbeta, 0, k, s))
+    return rc;
+  return bn_bwd_apply_launch(dtype, dA, a_or_null, y, coef, coef + C, k, dy, dres, 0, (long)rows, C, s);
+}
+
+int d3f_maxpool3x3s2_forward(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
+                             int C, void* stream) {
+  D3F_CHECK(in && out && idx, "maxpool: null argument");
+  return maxpool3x3s2_fwd_launch(dtype, in, out, idx, B, H, W, C, (hipStream_t)stream);
+}
+int d3f_maxpool3x3s2_backward(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
+                              int B, int H, int W, int C, void* stream) {
+  D3F_CHECK(dout && idx && din, "maxpool: null argument");
+  return maxpool3x3s2_bwd_launch(dtype, dout, idx, din, accumulate, B, H, W, C, (hipStream_t)stream);
+}
+int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int Hlow, int Wlow, int C,
+                            void* stream) {
+  D3F_CHECK(dfull && dlow, "upsample2x_backward: null argument");
+  return sum2x2_launch(dtype, dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
+}
+int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream) {
+  D3F_CHECK(in && out && Cpad >= C, "nchw_to_nhwc: argument");
+  return nchw_to_nhwc_launch(dtype, in, out, B, C, H, W, Cpad, (hipStream_t)stream);
+}
+int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad, void* stream) {
+  D3F_CHECK(in && out && Cpad >= C, "nhwc_to_nchw: argument");
+  return nhwc_to_nchw_launch(dtype, in, out, B, C, H, W, Cpad, (hipStream_t)stream);
+}
+
+// ---- training-step arithmetic ---------------------------------------------------------------
+int d3f_noise_blend(const float* x, const float* noise, const float* y_uniform, float lam, float* out,
+                    float* r_out_or_null, int B, int64_t per_image, void* stream) {
+  D3F_CHECK(x && noise && y_uniform && out, "noise_blend: null argument");
+  return noise_blend_launch(x, noise, y_uniform, lam, out, r_out_or_null, B, (long)per_image,
+                            (hipStream_t)stream);
+}
+size_t d3f_mse_ssim_loss_workspace_bytes(int B, int H, int W) {
+  return loss_workspace_floats(B, H, W) * sizeof(float);
+}
+int d3f_mse_ssim_loss(const float* pred, const float* target, float input_min, float input_max,
+                      float* loss_out, float* grad_pred, void* workspace, int B, int H, int W, void* stream) {
+  D3F_CHECK(pred && target && loss_out && grad_pred && workspace, "mse_ssim_loss: null argument");
+  return mse_ssim_loss_launch(pred, target, input_min, input_max, loss_out, grad_pred,
+                              reinterpret_cast<float*>(workspace), B, H, W, (hipStream_t)stream);
+}
+int d3f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  D3F_CHECK(params && grads && exp_avg && exp_avg_sq, "adam_step: null argument");
+  return adam_step_launch(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, step,
+                          grad_scale, (hipStream_t)stream);
+}
+int d3f_ema_lerp(float* ema, const float* online, int64_t n, float weight, void* stream) {
+  D3F_CHECK(ema && online, "ema_lerp: null argument");
+  return ema_lerp_launch(ema, online, (long)n, weight, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Shared declarations for libd3f_hip.so (gfx950 / CDNA4 only).
+//
+// Internal activation layout: NHWC ("pixel-major"): [B][H][W][C], C a multiple of 4 (f32)
+// or 8 (bf16) so every pixel's channel run is a whole number of 16-byte vectors.  The
+// drop-in boundary (include/d3f_hip.h) is NCHW fp32, converted at the network's first and
+// last kernel only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace d3f {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+}  // namespace d3f
+#ifndef D3F_F32
+#define D3F_F32 0  // same values as include/d3f_hip.h
+#define D3F_BF16 1
+#endif
+namespace d3f {
+
+// thread-local error string (c_api.cpp)
+int set_error(int code, const char* fmt, ...);
+#define D3F_CHECK(cond, ...)                              \
+  do {                                                    \
+    if (!(cond)) return ::d3f::set_error(-1, __VA_ARGS__); \
+  } while (0)
+#define D3F_HIP(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return ::d3f::set_error(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                    \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VE = 4;    // elements per 16-byte vector
+  static constexpr int BKE = 32;  // elements per 128-byte k-row
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VE = 8;
+  static constexpr int BKE = 64;
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (forward and data-gradient): conv_igemm.hip
+// ---------------------------------------------------------------------------------------
+enum ConvMode : int {
+  CONV_RAW_STATS = 0,   // store raw NHWC conv output (+ per-channel partial sum / sumsq)
+  CONV_HEAD_NCHW = 1,   // + bias, store NCHW fp32 (network boundary)
+  CONV_EVAL_FUSED = 2,  // y*scale + shift (+res) (relu) -> NHWC   (eval-mode BN folded)
+  CONV_DGRAD = 3,       // dual-destination NHWC store with optional accumulate
+};
+
+struct ConvParams {
+  const void* src0;  // NHWC [B][H0s][W0s][C0]
+  const void* src1;  // NHWC [B][Hv][Wv][C1] (channel-concatenated after src0) or null
+  const void* w;     // packed weights [CoutPad][Kpad], k = (kh*KW + kw)*Cin + c
+  void* out0;
+  void* out1;
+  float* stats;        // [tiles_m][CoutPad][2] or null           (CONV_RAW_STATS)
+  const float* scale;  // per-out-channel scale (EVAL) / bias (HEAD)
+  const float* shift;  // per-out-channel shift (EVAL)
+  const void* res;     // residual NHWC (EVAL) or null
+  int B, Hv, Wv;       // virtual input extent (after upsample / zero insertion)
+  int C0, C1;          // C0 + C1 = Cin (padded to a vector multiple)
+  int H0s, W0s;        // physical extent of src0 = (Hv, Wv) >> shift0
+  int shift0;          // 1: src0 is read at (iy>>1, ix>>1)   (nearest x2 upsample)
+  int zi;              // 1 (with shift0): only even (iy, ix) exist (zero insertion = dgrad of stride 2)
+  int Ho, Wo, Cout;    // output extent, real output channels
+  int CoutPad, Kpad;
+  int KH, KW, stride, pad;
+  int M;               // B*Ho*Wo
+  int tiles_m, tiles_n;
+  int out_c0;          // CONV_DGRAD: channels [0,out_c0) -> out0, the rest -> out1
+  int acc0, acc1;      // CONV_DGRAD: read-modify-write destinations
+  int mode;
+  int relu;
+};
+
+struct ConvTile {
+  int BM, BN;
+};
+// chooses the tile configuration for a problem; tiles_m/tiles_n are filled in p.
+int conv_igemm_plan(ConvParams& p, int dtype);
+int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient: conv_wgrad.hip
+// ---------------------------------------------------------------------------------------
+struct WgradParams {
+  const void* dy;    // NHWC [B][Ho][Wo][Cout] (T)
+  const void* src0;  // conv input, same gather description as ConvParams
+  const void* src1;
+  float* partial;    // [splits][Cout][KH*KW][Cin] fp32 slabs
+  int B, Hv, Wv, C0, C1, H0s, W0s, shift0;
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad;
+  int M;        // B*Ho*Wo
+  int splits;   // pixel slabs
+  int chunks_per_split;  // 32-pixel chunks per slab
+  int tiles_co, tiles_ci;
+};
+int wgrad_plan(WgradParams& p, int dtype);  // fills splits/tiles; returns 0
+size_t wgrad_partial_floats(const WgradParams& p);
+int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
+// sums the slabs [splits][CoutP][KH*KW][Cin] and writes the PyTorch-layout gradient
+// [Cout][CinReal][KH][KW] (fp32), dropping padded channels
+int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
+                        int KH, int KW, float* dw, int accumulate, hipStream_t stream);
+
+}  // namespace d3f

@@ -1,0 +1,258 @@
+// Convolution weight gradient on the matrix cores.
+//
+//   dW[co][tap][ci] = sum_m dY[m][co] * V[m, tap][ci]       m = (b, oy, ox)
+//
+// i.e. per filter tap a GEMM whose reduction runs over output pixels.  In NHWC both
+// operands are stored pixel-major, which is exactly the k-major image the f32 MFMA wants
+// (lane l supplies element [k = l>>5][i = l&31]): tiles are staged in LDS as [pixel][channel]
+// rows and fragments are read with conflict-free ds_read_b32.  V is gathered like the
+// forward A operand (two concatenated sources, optional nearest x2 up-sample), so the
+// decoder's upsample+cat never exists in memory in the backward pass either.
+//
+// The pixel range is cut into `splits` slabs (one grid.y each) that write fp32 partial
+// slabs; wgrad_reduce sums them in a fixed order (bitwise reproducible, no float atomics)
+// and scatters into the PyTorch [Cout][Cin][KH][KW] gradient layout.
+// Replaces the conv weight-gradient ATen/cuDNN kernels autograd runs under
+// loss.backward() for the reference's U-Net.
+#include "common.h"
+
+namespace d3f {
+
+constexpr int KP = 32;  // pixels per k-chunk
+
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  static_assert(sizeof(T) == 4, "f32 only (bf16 wgrad: later round)");
+  constexpr int TM = BMW / WGM, TN = BNW / WGN, FM = TM / 32, FN = TN / 32;
+  constexpr int LY = BMW + 4, LX = BNW + 4;  // LDS row strides (floats), 16-B aligned rows
+  constexpr int VY = BMW / 4, VX = BNW / 4;  // 16-byte vectors per row
+  constexpr int NVY = KP * VY / 256, NVX = KP * VX / 256;
+  static_assert(WGM * WGN * KSPLIT == 4, "4 waves");
+  static_assert(NVY >= 1 && NVX >= 1, "tile too small for 256 loader threads");
+  constexpr int RED = (KSPLIT > 1) ? KSPLIT * 32 * 32 : 1;
+  constexpr int LDS_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* Ys = lds;
+  float* Xs = lds + KP * LY;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % KSPLIT;
+  const int wmn = wave / KSPLIT;
+  const int wm = wmn / WGN, wn = wmn % WGN;
+
+  int bid = blockIdx.x;
+  const int tile_ci = bid % p.tiles_ci;
+  bid /= p.tiles_ci;
+  const int tile_co = bid % p.tiles_co;
+  const int tap = bid / p.tiles_co;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;
+  const int split = blockIdx.y;
+  const int Cin = p.C0 + p.C1;
+
+  const float* __restrict__ dy = reinterpret_cast<const float*>(p.dy);
+  const float* __restrict__ src0 = reinterpret_cast<const float*>(p.src0);
+  const float* __restrict__ src1 = reinterpret_cast<const float*>(p.src1);
+
+  // loader roles
+  const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*(256/VY)
+  const int xcv = tid % VX, xrow0 = tid / VX;
+  constexpr int YRS = 256 / VY, XRS = 256 / VX;
+  const int yco = co0 + ycv * 4;
+  const int xci = ci0 + xcv * 4;
+  const bool yvalid_c = yco < p.Cout;
+  const bool xvalid_c = xci < Cin;
+  const bool from0 = xci < p.C0;
+  const float* __restrict__ xsrc = from0 ? src0 + xci : src1 + (xci - p.C0);
+  const int Cs = from0 ? p.C0 : p.C1;
+  const int sh = from0 ? p.shift0 : 0;
+  const int Hs = from0 ? p.H0s : p.Hv;
+  const int Ws = from0 ? p.W0s : p.Wv;
+  const int HoWo = p.Ho * p.Wo;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int chunk_begin = split * p.chunks_per_split;
+  int chunk_end = chunk_begin + p.chunks_per_split;
+  const int total_chunks = (p.M + KP - 1) / KP;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+  float4 ry[NVY], rx[NVX];
+  auto load_chunk = [&](int ch) {
+    const int pix0 = ch * KP;
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int m = pix0 + yrow0 + i * YRS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yvalid_c && m < p.M) v = *reinterpret_cast<const float4*>(dy + (long)m * p.Cout + yco);
+      ry[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int m = pix0 + xrow0 + i * XRS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xvalid_c && m < p.M) {
+        const int b = m / HoWo;
+        const int r = m - b * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        const int iy = oy * p.stride - p.pad + kh;
+        const int ix = ox * p.stride - p.pad + kw;
+        if ((unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv) {
+          const long pix = ((long)b * Hs + (iy >> sh)) * Ws + (ix >> sh);
+          v = *reinterpret_cast<const float4*>(xsrc + pix * Cs);
+        }
+      }
+      rx[i] = v;
+    }
+  };
+
+  if (chunk_begin < chunk_end) load_chunk(chunk_begin);
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+#pragma unroll
+    for (int i = 0; i < NVY; ++i)
+      *reinterpret_cast<float4*>(&Ys[(yrow0 + i * YRS) * LY + ycv * 4]) = ry[i];
+#pragma unroll
+    for (int i = 0; i < NVX; ++i)
+      *reinterpret_cast<float4*>(&Xs[(xrow0 + i * XRS) * LX + xcv * 4]) = rx[i];
+    __syncthreads();
+    if (ch + 1 < chunk_end) load_chunk(ch + 1);
+#pragma unroll
+    for (int kk = wk; kk < KP / 2; kk += KSPLIT) {
+      const int k = 2 * kk + fh;
+      float a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = Ys[k * LY + wm * TM + i * 32 + fr];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = Xs[k * LX + wn * TN + j * 32 + fr];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int taps = p.KH * p.KW;
+  float* __restrict__ slab = p.partial + (long)split * p.Cout * taps * Cin;
+  if (KSPLIT > 1) {
+    // the 4 waves hold partial sums of the same 32x32 tile: reduce through LDS
+    float* red = lds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co_l = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      red[(wk * 32 + co_l) * 32 + fr] = acc[0][0][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < KSPLIT; ++w) s += red[w * 1024 + e];
+      const int co = co0 + (e >> 5), ci = ci0 + (e & 31);
+      if (co < p.Cout && ci < Cin) slab[((long)co * taps + tap) * Cin + ci] = s;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int ci = ci0 + wn * TN + j * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (co < p.Cout && ci < Cin) slab[((long)co * taps + tap) * Cin + ci] = acc[i][j][r];
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           int splits, int CoutP, int Cout, int Cin,
+                                                           int CinReal, int taps,
+                                                           float* __restrict__ dw, int accumulate) {
+  const long n = (long)CoutP * taps * Cin;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int ci = (int)(e % Cin);
+    const long t = e / Cin;
+    const int tap = (int)(t % taps);
+    const int co = (int)(t / taps);
+    if (ci >= CinReal || co >= Cout) continue;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(long)k * n + e];
+    float* dst = dw + ((long)co * CinReal + ci) * taps + tap;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+struct WTile {
+  int bm, bn;
+};
+static WTile pick_wtile(const WgradParams& p) {
+  const int cin = p.C0 + p.C1;
+  if (p.Cout >= 128 && cin >= 128) return {128, 128};
+  if (p.Cout > 32 && cin > 32) return {64, 64};
+  return {32, 32};
+}
+
+int wgrad_plan(WgradParams& p, int dtype) {
+  D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
+  D3F_CHECK((p.C0 % 4) == 0 && (p.C1 % 4) == 0 && (p.Cout % 4) == 0,
+            "wgrad: channels (%d,%d,%d) must be multiples of 4", p.C0, p.C1, p.Cout);
+  D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
+  D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
+  const WTile t = pick_wtile(p);
+  const int cin = p.C0 + p.C1;
+  p.tiles_co = cdiv(p.Cout, t.bm);
+  p.tiles_ci = cdiv(cin, t.bn);
+  const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW;
+  const int total_chunks = cdiv(p.M, KP);
+  long splits = (1024 + base - 1) / base;  // aim at ~4 blocks per CU
+  const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.chunks_per_split = cdiv(total_chunks, splits);
+  p.splits = cdiv(total_chunks, p.chunks_per_split);
+  return 0;
+}
+
+size_t wgrad_partial_floats(const WgradParams& p) {
+  return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+}
+
+int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+  D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
+  if (p.M == 0) return 0;
+  const WTile t = pick_wtile(p);
+  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits), block(256);
+  if (t.bm == 128)
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 128, 128, 2, 2, 1>), grid, block, 0, stream, p);
+  else if (t.bm == 64)
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 2, 2, 1>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, 32, 1, 1, 4>), grid, block, 0, stream, p);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
+                        int KH, int KW, float* dw, int accumulate, hipStream_t stream) {
+  const long n = (long)CoutP * KH * KW * Cin;
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, splits, CoutP,
+                     Cout, Cin, CinReal, KH * KW, dw, accumulate);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace d3f

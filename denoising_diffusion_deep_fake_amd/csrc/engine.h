@@ -1,0 +1,120 @@
+// Whole-network engine for Unet(resnet18|resnet34): a static plan of the layer graph
+// (units = conv [+ BatchNorm + ReLU + residual]), the workspace layout and the forward /
+// backward launch sequences.  No device memory is allocated here: the caller (PyTorch)
+// owns params, grads, BN statistics and one workspace buffer; the engine only enqueues
+// kernels on the caller's stream.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "pointwise.h"
+
+namespace d3f {
+
+struct TensorD {
+  size_t off = 0;  // bytes into the workspace
+  int H = 0, W = 0, C = 0;
+  long elems(int B) const { return (long)B * H * W * C; }
+};
+
+struct ParamInfo {
+  std::string name;
+  int shape[4];
+  int ndim;
+  long offset;  // floats into the flat parameter (and gradient) buffer
+  long numel;
+};
+
+struct BnInfo {
+  std::string prefix;  // module path, e.g. "encoder.layer1.0.bn1"
+  int C;
+  long rm_off, rv_off;  // floats into the flat BN-statistics buffer
+};
+
+struct Unit {
+  std::string conv_name, bn_name;
+  int Cout = 0, CinReal = 0, C0 = 0, C1 = 0, KH = 0, KW = 0, stride = 1, pad = 0, up0 = 0;
+  int Hv = 0, Wv = 0, Ho = 0, Wo = 0;
+  int in0 = -1, in1 = -1, y = -1, a = -1;
+  bool bn = true, bias = false, relu = true, apply = true, need_dgrad = true;
+  int res_tensor = -1, res_unit = -1;
+  long w_off = -1, bias_off = -1, g_off = -1, b_off = -1, rm_off = -1, rv_off = -1;
+  size_t wf_off = 0, wd_off = 0;  // packed weights (bytes into workspace)
+  int CoutPad = 0, Kpad = 0, CinRows = 0, KpadD = 0, CoutD = 0;
+  size_t coef_off = 0;  // bytes: mean[C] invstd[C] scale[C] shift[C] k[3C]
+  int segment = 0;      // backward bucket this unit belongs to
+  ConvParams fwd{}, dgrad{};
+  WgradParams wg{};
+  int Cin() const { return C0 + C1; }
+};
+
+enum BwdKind { BW_HEAD, BW_UNIT, BW_SUM2X2, BW_POOL };
+struct BwdOp {
+  BwdKind kind;
+  int unit = -1;
+  // BW_UNIT
+  int dA = -1;          // gradient tensor wrt the unit's output activation (grad id)
+  bool mask = true;     // apply the ReLU mask of unit.a
+  int dres = -1;        // grad tensor receiving dz (identity / downsample path) or -1
+  bool dres_acc = false;
+  int dst0 = -1, dst1 = -1;  // dgrad destinations (grad ids); dst0 may be the full-res scratch
+  bool acc0 = false, acc1 = false;
+  bool dst0_is_full_scratch = false;
+  // BW_SUM2X2: src = full-res scratch (C channels at 2H x 2W) -> dst0
+  int C = 0, Hl = 0, Wl = 0;
+  // BW_POOL: dA (pooled grad) -> dst0 (acc0)
+  int segment = 0;
+};
+
+class UnetEngine {
+ public:
+  int build(const char* encoder, int in_channels, int classes, int B, int H, int W, int dtype);
+
+  int pack_weights(const float* params, void* ws, hipStream_t s) const;
+  int forward(const float* params, float* bnstats, const float* x, float* out, void* ws, int training,
+              hipStream_t s) const;
+  int backward(const float* params, const float* dout, float* grads, void* ws, int seg_begin,
+               int seg_end, hipStream_t s) const;
+  int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
+
+  std::vector<ParamInfo> params;
+  std::vector<BnInfo> bns;
+  long param_floats = 0, bnstat_floats = 0;
+  size_t workspace_bytes = 0;
+  int num_segments = 4;
+  long seg_grad_begin[8] = {0}, seg_grad_end[8] = {0};
+  int B = 0, H = 0, W = 0, dtype = 0, in_channels = 3, classes = 3;
+  double fwd_flops = 0, bwd_flops = 0;  // algorithmic conv FLOPs (2*MAC) per call
+  std::vector<Unit> units;
+
+ private:
+  int esize() const { return dtype == D3F_F32 ? 4 : 2; }
+  int ve() const { return dtype == D3F_F32 ? 4 : 8; }
+  int bke() const { return dtype == D3F_F32 ? 32 : 64; }
+  int new_tensor(int H_, int W_, int C_);
+  int new_grad(int tensor_id);
+  size_t alloc(size_t bytes);
+  int add_unit(const std::string& conv_name, const std::string& bn_name, int in0, int in1, int up0,
+               int Cout, int k, int stride, int pad, bool bn, bool bias, bool relu, bool apply,
+               int segment);
+  int plan_unit(Unit& u);
+  void bind(ConvParams& p, const Unit& u, char* ws) const;
+
+  std::vector<TensorD> tensors;   // activations
+  std::vector<TensorD> gtensors;  // activation gradients
+  std::vector<int> grad_of;       // tensor id -> grad id or -1
+  std::vector<bool> grad_init;    // plan-time: has a writer been emitted yet
+  std::vector<BwdOp> bwd_ops;
+  std::vector<int> fwd_order_;    // unit ids in execution order, -1 = max-pool
+  size_t ws_top = 0;
+  int t_x = -1, t_pool = -1, head = -1, conv1 = -1;
+  size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dy_off = 0, dz_off = 0, dfull_off = 0,
+         wpart_off = 0, dyh_off = 0, bsum_off = 0;
+  size_t stats_bytes = 0, bnpart_bytes = 0, dy_bytes = 0, dz_bytes = 0, dfull_bytes = 0, wpart_bytes = 0;
+};
+
+int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
+                            hipStream_t stream);
+
+}  // namespace d3f

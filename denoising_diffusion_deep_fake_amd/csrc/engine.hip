@@ -1,0 +1,565 @@
+// Whole-network plan and launch sequences for Unet(resnet18|resnet34) -- the network the
+// reference instantiates at d3f/train_denoiser/lit_module.py:46-52 and
+// d3f/train_deep_fake/lit_module.py:53-59 (structure: SURVEY.md Appendix A.1).
+//
+// Parameter order (flat buffer) = torch named_parameters() order of that module tree, so the
+// Python side can expose ordinary nn.Parameters that are views into one flat buffer and keep
+// smp-compatible state_dict keys.
+#include "engine.h"
+
+#include <cstring>
+
+namespace d3f {
+
+// ------------------------------------------------------------------------------------------
+// tiny reduction used for the head's bias gradient: out[c] = sum_{b,hw} x[b][c][hw]
+// ------------------------------------------------------------------------------------------
+constexpr int CS_PARTS = 64;
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int B,
+                                                                  int C, long HW,
+                                                                  float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int c = blockIdx.y, part = blockIdx.x;
+  const long total = (long)B * HW;
+  float s = 0.f;
+  for (long i = (long)part * 256 + threadIdx.x; i < total; i += (long)CS_PARTS * 256) {
+    const long b = i / HW, p = i - b * HW;
+    s += x[(b * C + c) * HW + p];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[c * CS_PARTS + part] = red[0];
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int C,
+                                         float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < CS_PARTS; ++i) s += (double)partial[c * CS_PARTS + i];
+  out[c] = (float)s;
+}
+int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PARTS, C), dim3(256), 0, stream, x, B, C, HW,
+                     partial);
+  D3F_HIP(hipGetLastError());
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, partial, C, out);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+size_t UnetEngine::alloc(size_t bytes) {
+  const size_t off = ws_top;
+  ws_top += (size_t)round_up((long)bytes, 256);
+  return off;
+}
+
+int UnetEngine::new_tensor(int H_, int W_, int C_) {
+  TensorD t;
+  t.H = H_; t.W = W_; t.C = C_;
+  t.off = alloc((size_t)t.elems(B) * esize());
+  tensors.push_back(t);
+  grad_of.push_back(-1);
+  return (int)tensors.size() - 1;
+}
+
+int UnetEngine::new_grad(int tid) {
+  if (grad_of[tid] >= 0) return grad_of[tid];
+  TensorD g = tensors[tid];
+  g.off = alloc((size_t)g.elems(B) * esize());
+  gtensors.push_back(g);
+  grad_init.push_back(false);
+  grad_of[tid] = (int)gtensors.size() - 1;
+  return grad_of[tid];
+}
+
+static void add_param(std::vector<ParamInfo>& ps, long& top, const std::string& name, int ndim,
+                      int s0, int s1, int s2, int s3, long* off_out) {
+  ParamInfo p;
+  p.name = name;
+  p.ndim = ndim;
+  p.shape[0] = s0; p.shape[1] = s1; p.shape[2] = s2; p.shape[3] = s3;
+  p.numel = (long)s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1) * (ndim > 3 ? s3 : 1);
+  p.offset = top;
+  top += p.numel;
+  *off_out = p.offset;
+  ps.push_back(p);
+}
+
+int UnetEngine::add_unit(const std::string& conv_name, const std::string& bn_name, int in0, int in1,
+                         int up0, int Cout, int k, int stride, int pad, bool bn, bool bias, bool relu,
+                         bool apply, int segment) {
+  Unit u;
+  u.conv_name = conv_name;
+  u.bn_name = bn_name;
+  u.in0 = in0; u.in1 = in1; u.up0 = up0;
+  u.Cout = Cout; u.KH = u.KW = k; u.stride = stride; u.pad = pad;
+  u.bn = bn; u.bias = bias; u.relu = relu; u.apply = apply; u.segment = segment;
+  const TensorD& t0 = tensors[in0];
+  u.C0 = t0.C;
+  u.Hv = t0.H << up0;
+  u.Wv = t0.W << up0;
+  u.C1 = in1 >= 0 ? tensors[in1].C : 0;
+  D3F_CHECK(in1 < 0 || (tensors[in1].H == u.Hv && tensors[in1].W == u.Wv),
+            "unit %s: skip extent mismatch", conv_name.c_str());
+  u.CinReal = (in0 == t_x) ? in_channels : u.Cin();
+  u.Ho = (u.Hv + 2 * pad - k) / stride + 1;
+  u.Wo = (u.Wv + 2 * pad - k) / stride + 1;
+  u.need_dgrad = (in0 != t_x);
+  D3F_CHECK(stride == 1 || (u.Hv % 2 == 0 && u.Wv % 2 == 0 && u.Ho * 2 == u.Hv && u.Wo * 2 == u.Wv),
+            "unit %s: stride-2 conv needs an even extent", conv_name.c_str());
+
+  add_param(params, param_floats, conv_name + ".weight", 4, Cout, u.CinReal, k, k, &u.w_off);
+  if (bias) add_param(params, param_floats, conv_name + ".bias", 1, Cout, 1, 1, 1, &u.bias_off);
+  if (bn) {
+    add_param(params, param_floats, bn_name + ".weight", 1, Cout, 1, 1, 1, &u.g_off);
+    add_param(params, param_floats, bn_name + ".bias", 1, Cout, 1, 1, 1, &u.b_off);
+    BnInfo bi;
+    bi.prefix = bn_name;
+    bi.C = Cout;
+    bi.rm_off = bnstat_floats;
+    bi.rv_off = bnstat_floats + Cout;
+    bnstat_floats += 2L * Cout;
+    u.rm_off = bi.rm_off;
+    u.rv_off = bi.rv_off;
+    bns.push_back(bi);
+    u.y = new_tensor(u.Ho, u.Wo, Cout);
+    u.a = apply ? new_tensor(u.Ho, u.Wo, Cout) : -1;
+    u.coef_off = alloc((size_t)7 * Cout * sizeof(float));
+  }
+  u.CoutPad = (int)round_up(Cout, 16);
+  u.Kpad = (int)round_up((long)k * k * u.Cin(), bke());
+  u.wf_off = alloc((size_t)u.CoutPad * u.Kpad * esize());
+  u.CoutD = (int)round_up(Cout, ve());
+  if (u.need_dgrad) {
+    u.KpadD = (int)round_up((long)k * k * u.CoutD, bke());
+    u.CinRows = (int)round_up(u.Cin(), 16);
+    u.wd_off = alloc((size_t)u.CinRows * u.KpadD * esize());
+  }
+  units.push_back(u);
+  return (int)units.size() - 1;
+}
+
+int UnetEngine::plan_unit(Unit& u) {
+  ConvParams& f = u.fwd;
+  std::memset(&f, 0, sizeof(f));
+  f.B = B; f.Hv = u.Hv; f.Wv = u.Wv; f.C0 = u.C0; f.C1 = u.C1;
+  f.H0s = u.Hv >> u.up0; f.W0s = u.Wv >> u.up0; f.shift0 = u.up0; f.zi = 0;
+  f.Ho = u.Ho; f.Wo = u.Wo; f.Cout = u.Cout; f.CoutPad = u.CoutPad; f.Kpad = u.Kpad;
+  f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;
+  f.M = B * u.Ho * u.Wo;
+  if (int rc = conv_igemm_plan(f, dtype)) return rc;
+  const double macs = (double)f.M * u.Cout * u.KH * u.KW * u.CinReal;
+  fwd_flops += 2.0 * macs;
+  bwd_flops += 2.0 * macs;  // weight gradient
+  if (u.bn) {
+    const size_t sb = (size_t)f.tiles_m * u.CoutPad * 2 * sizeof(float);
+    if (sb > stats_bytes) stats_bytes = sb;
+    const size_t pb = (size_t)bn_bwd_reduce_blocks((long)f.M, u.Cout, dtype) * u.Cout * 2 * sizeof(float);
+    if (pb > bnpart_bytes) bnpart_bytes = pb;
+  }
+  const size_t dyb = (size_t)f.M * u.CoutD * esize();
+  if (dyb > dy_bytes) dy_bytes = dyb;
+  if (!u.apply && u.bn && dyb > dz_bytes) dz_bytes = dyb;
+
+  WgradParams& g = u.wg;
+  std::memset(&g, 0, sizeof(g));
+  g.B = B; g.Hv = u.Hv; g.Wv = u.Wv; g.C0 = u.C0; g.C1 = u.C1;
+  g.H0s = f.H0s; g.W0s = f.W0s; g.shift0 = u.up0;
+  g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
+  g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = f.M;
+  if (dtype == D3F_F32) {
+    if (int rc = wgrad_plan(g, dtype)) return rc;
+    const size_t wb = wgrad_partial_floats(g) * sizeof(float);
+    if (wb > wpart_bytes) wpart_bytes = wb;
+  }
+
+  if (u.need_dgrad) {
+    ConvParams& d = u.dgrad;
+    std::memset(&d, 0, sizeof(d));
+    const int s2 = u.stride == 2 ? 1 : 0;
+    d.B = B; d.Hv = u.Hv; d.Wv = u.Wv;  // extent of the (zero-inserted) dY == extent of dX
+    D3F_CHECK(s2 || (u.Ho == u.Hv && u.Wo == u.Wv), "unit %s: dgrad expects a 'same' conv",
+              u.conv_name.c_str());
+    d.C0 = u.CoutD; d.C1 = 0;
+    d.H0s = u.Ho; d.W0s = u.Wo; d.shift0 = s2; d.zi = s2;
+    d.Ho = u.Hv; d.Wo = u.Wv; d.Cout = u.Cin(); d.CoutPad = u.CinRows; d.Kpad = u.KpadD;
+    d.KH = u.KH; d.KW = u.KW; d.stride = 1; d.pad = u.KH - 1 - u.pad;
+    d.M = B * u.Hv * u.Wv;
+    d.mode = CONV_DGRAD;
+    d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
+    if (int rc = conv_igemm_plan(d, dtype)) return rc;
+    bwd_flops += 2.0 * macs;
+    if (u.up0) {
+      const size_t fb = (size_t)d.M * u.C0 * esize();
+      if (fb > dfull_bytes) dfull_bytes = fb;
+    }
+  }
+  return 0;
+}
+
+int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B_, int H_, int W_,
+                      int dtype_) {
+  D3F_CHECK(dtype_ == D3F_F32 || dtype_ == D3F_BF16, "unet: dtype %d", dtype_);
+  D3F_CHECK(B_ >= 1 && H_ >= 32 && W_ >= 32, "unet: bad shape B=%d H=%d W=%d", B_, H_, W_);
+  D3F_CHECK(H_ % 32 == 0 && W_ % 32 == 0,
+            "Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.",
+            H_, W_);
+  D3F_CHECK(in_channels_ >= 1 && in_channels_ <= 8 && classes_ >= 1 && classes_ <= 16,
+            "unet: in_channels=%d classes=%d unsupported", in_channels_, classes_);
+  int nblocks[4];
+  if (std::strcmp(encoder, "resnet34") == 0) { nblocks[0] = 3; nblocks[1] = 4; nblocks[2] = 6; nblocks[3] = 3; }
+  else if (std::strcmp(encoder, "resnet18") == 0) { nblocks[0] = nblocks[1] = nblocks[2] = nblocks[3] = 2; }
+  else return set_error(-1, "Wrong encoder name `%s`, supported encoders: ['resnet18', 'resnet34']", encoder);
+  B = B_; H = H_; W = W_; dtype = dtype_; in_channels = in_channels_; classes = classes_;
+  D3F_CHECK((long)B * H * W * 64 < (1L << 31), "unet: activation too large for 32-bit pixel indices");
+
+  // ---- graph --------------------------------------------------------------------------
+  t_x = new_tensor(H, W, (int)round_up(in_channels, ve()));
+  conv1 = add_unit("encoder.conv1", "encoder.bn1", t_x, -1, 0, 64, 7, 2, 3, true, false, true, true, 3);
+  if (conv1 < 0) return conv1;
+  const int f1 = units[conv1].a;
+  t_pool = new_tensor(H / 4, W / 4, 64);
+  pool_idx_off = alloc((size_t)tensors[t_pool].elems(B));
+  int cur = t_pool, inpl = 64;
+  int feat[6] = {-1, f1, -1, -1, -1, -1};
+  struct Blk { int u1, u2, ud; };
+  std::vector<Blk> enc_blocks;
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = 64 << (li - 1);
+    const int seg = li == 4 ? 1 : (li == 3 ? 2 : 3);
+    for (int bi = 0; bi < nblocks[li - 1]; ++bi) {
+      const int stride = (bi == 0 && li > 1) ? 2 : 1;
+      const std::string pre = "encoder.layer" + std::to_string(li) + "." + std::to_string(bi);
+      Blk blk;
+      blk.u1 = add_unit(pre + ".conv1", pre + ".bn1", cur, -1, 0, planes, 3, stride, 1, true, false, true, true, seg);
+      if (blk.u1 < 0) return blk.u1;
+      blk.u2 = add_unit(pre + ".conv2", pre + ".bn2", units[blk.u1].a, -1, 0, planes, 3, 1, 1, true, false, true, true, seg);
+      if (blk.u2 < 0) return blk.u2;
+      blk.ud = -1;
+      if (stride != 1 || inpl != planes) {
+        blk.ud = add_unit(pre + ".downsample.0", pre + ".downsample.1", cur, -1, 0, planes, 1, stride, 0, true, false, false, false, seg);
+        if (blk.ud < 0) return blk.ud;
+        units[blk.u2].res_unit = blk.ud;
+      } else {
+        units[blk.u2].res_tensor = cur;
+      }
+      enc_blocks.push_back(blk);
+      cur = units[blk.u2].a;
+      inpl = planes;
+    }
+    feat[li + 1] = cur;
+  }
+  const int dec_out[5] = {256, 128, 64, 32, 16};
+  const int skips[5] = {feat[4], feat[3], feat[2], feat[1], -1};
+  int x = feat[5];
+  struct DBlk { int u1, u2; };
+  std::vector<DBlk> dec_blocks;
+  for (int i = 0; i < 5; ++i) {
+    const std::string pre = "decoder.blocks." + std::to_string(i);
+    DBlk d;
+    d.u1 = add_unit(pre + ".conv1.0", pre + ".conv1.1", x, skips[i], 1, dec_out[i], 3, 1, 1, true, false, true, true, 0);
+    if (d.u1 < 0) return d.u1;
+    d.u2 = add_unit(pre + ".conv2.0", pre + ".conv2.1", units[d.u1].a, -1, 0, dec_out[i], 3, 1, 1, true, false, true, true, 0);
+    if (d.u2 < 0) return d.u2;
+    dec_blocks.push_back(d);
+    x = units[d.u2].a;
+  }
+  head = add_unit("segmentation_head.0", "", x, -1, 0, classes, 3, 1, 1, false, true, false, false, 0);
+  if (head < 0) return head;
+
+  for (auto& u : units)
+    if (int rc = plan_unit(u)) return rc;
+
+  // ---- backward schedule (static: first writer writes, later writers accumulate) --------
+  auto grad_dst = [&](int tid, bool* acc) {
+    const int g = new_grad(tid);
+    *acc = grad_init[g];
+    grad_init[g] = true;
+    return g;
+  };
+  auto emit_unit = [&](int ui, int dA, bool mask, int dres, bool dres_acc) {
+    const Unit& u = units[ui];
+    BwdOp op;
+    op.kind = BW_UNIT; op.unit = ui; op.dA = dA; op.mask = mask; op.dres = dres; op.dres_acc = dres_acc;
+    op.segment = u.segment;
+    if (u.need_dgrad) {
+      if (u.up0) {
+        op.dst0_is_full_scratch = true;
+        if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
+      } else {
+        op.dst0 = grad_dst(u.in0, &op.acc0);
+      }
+    }
+    bwd_ops.push_back(op);
+    if (u.need_dgrad && u.up0) {
+      BwdOp s;
+      s.kind = BW_SUM2X2; s.unit = ui; s.C = u.C0; s.Hl = u.Hv / 2; s.Wl = u.Wv / 2; s.segment = u.segment;
+      bool acc;
+      s.dst0 = grad_dst(u.in0, &acc);
+      D3F_CHECK(!acc, "plan: up-sampled tensor has two consumers");
+      bwd_ops.push_back(s);
+    }
+    return 0;
+  };
+  {
+    BwdOp h;
+    h.kind = BW_HEAD; h.unit = head; h.segment = 0;
+    h.dst0 = grad_dst(units[head].in0, &h.acc0);
+    bwd_ops.push_back(h);
+  }
+  for (int i = 4; i >= 0; --i) {
+    const DBlk& d = dec_blocks[i];
+    if (int rc = emit_unit(d.u2, grad_of[units[d.u2].a], true, -1, false)) return rc;
+    if (int rc = emit_unit(d.u1, grad_of[units[d.u1].a], true, -1, false)) return rc;
+  }
+  for (int bi = (int)enc_blocks.size() - 1; bi >= 0; --bi) {
+    const Blk& b = enc_blocks[bi];
+    const Unit& u2 = units[b.u2];
+    D3F_CHECK(grad_of[u2.a] >= 0, "plan: block output without gradient");
+    int dres;
+    bool dres_acc = false;
+    if (b.ud >= 0) dres = -2;  // dz scratch feeds the downsample branch
+    else dres = grad_dst(u2.res_tensor, &dres_acc);
+    if (int rc = emit_unit(b.u2, grad_of[u2.a], true, dres, dres_acc)) return rc;
+    if (int rc = emit_unit(b.u1, grad_of[units[b.u1].a], true, -1, false)) return rc;
+    if (b.ud >= 0)
+      if (int rc = emit_unit(b.ud, -2, false, -1, false)) return rc;
+  }
+  {
+    BwdOp p;
+    p.kind = BW_POOL; p.segment = 3;
+    p.dA = grad_of[t_pool];
+    D3F_CHECK(p.dA >= 0, "plan: pool output without gradient");
+    p.dst0 = grad_dst(f1, &p.acc0);
+    bwd_ops.push_back(p);
+  }
+  if (int rc = emit_unit(conv1, grad_of[f1], true, -1, false)) return rc;
+
+  // ---- scratch ------------------------------------------------------------------------
+  stats_off = alloc(stats_bytes);
+  bnpart_off = alloc(bnpart_bytes);
+  dy_off = alloc(dy_bytes);
+  dz_off = alloc(dz_bytes);
+  dfull_off = alloc(dfull_bytes);
+  wpart_off = alloc(wpart_bytes);
+  bsum_off = alloc((size_t)classes * CS_PARTS * sizeof(float));
+  workspace_bytes = ws_top;
+
+  // ---- gradient buckets (contiguous slices of the flat gradient, ready in this order) ----
+  long layer3_start = -1, layer4_start = -1, dec_start = -1;
+  for (const auto& p : params) {
+    if (layer3_start < 0 && p.name.rfind("encoder.layer3.", 0) == 0) layer3_start = p.offset;
+    if (layer4_start < 0 && p.name.rfind("encoder.layer4.", 0) == 0) layer4_start = p.offset;
+    if (dec_start < 0 && p.name.rfind("decoder.", 0) == 0) dec_start = p.offset;
+  }
+  num_segments = 4;
+  seg_grad_begin[0] = dec_start;     seg_grad_end[0] = param_floats;
+  seg_grad_begin[1] = layer4_start;  seg_grad_end[1] = dec_start;
+  seg_grad_begin[2] = layer3_start;  seg_grad_end[2] = layer4_start;
+  seg_grad_begin[3] = 0;             seg_grad_end[3] = layer3_start;
+  fwd_order_.clear();
+  fwd_order_.push_back(conv1);
+  fwd_order_.push_back(-1);  // max-pool
+  for (const auto& b : enc_blocks) {
+    fwd_order_.push_back(b.u1);
+    if (b.ud >= 0) fwd_order_.push_back(b.ud);
+    fwd_order_.push_back(b.u2);
+  }
+  for (const auto& d : dec_blocks) {
+    fwd_order_.push_back(d.u1);
+    fwd_order_.push_back(d.u2);
+  }
+  fwd_order_.push_back(head);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) const {
+  char* ws = reinterpret_cast<char*>(ws_);
+  for (const Unit& u : units) {
+    if (int rc = pack_weights_launch(dtype, params_ + u.w_off, u.Cout, u.CinReal, u.Cin(), u.KH, u.KW,
+                                     ws + u.wf_off, u.CoutPad, u.Kpad,
+                                     u.need_dgrad ? ws + u.wd_off : nullptr, u.CinRows, u.KpadD, s))
+      return rc;
+  }
+  return 0;
+}
+
+static inline float* coef_ptr(char* ws, const Unit& u, int which) {
+  return reinterpret_cast<float*>(ws + u.coef_off) + (long)which * u.Cout;
+}
+
+int UnetEngine::forward(const float* params_, float* bnstats, const float* x, float* out, void* ws_,
+                        int training, hipStream_t s) const {
+  char* ws = reinterpret_cast<char*>(ws_);
+  auto T = [&](int tid) { return ws + tensors[tid].off; };
+  if (int rc = nchw_to_nhwc_launch(dtype, x, T(t_x), B, in_channels, H, W, tensors[t_x].C, s)) return rc;
+  if (!training) {
+    for (const Unit& u : units)
+      if (u.bn)
+        if (int rc = bn_eval_coeff_launch(params_ + u.g_off, params_ + u.b_off, bnstats + u.rm_off,
+                                          bnstats + u.rv_off, 1e-5f, u.Cout, coef_ptr(ws, u, 2),
+                                          coef_ptr(ws, u, 3), s))
+          return rc;
+  }
+  for (int ui : fwd_order_) {
+    if (ui < 0) {
+      const TensorD& f1 = tensors[units[conv1].a];
+      if (int rc = maxpool3x3s2_fwd_launch(dtype, T(units[conv1].a), T(t_pool),
+                                           reinterpret_cast<uint8_t*>(ws + pool_idx_off), B, f1.H, f1.W,
+                                           f1.C, s))
+        return rc;
+      continue;
+    }
+    const Unit& u = units[ui];
+    ConvParams p = u.fwd;
+    p.src0 = T(u.in0);
+    p.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
+    p.w = ws + u.wf_off;
+    if (!u.bn) {  // segmentation head
+      p.mode = CONV_HEAD_NCHW;
+      p.out0 = out;
+      p.scale = params_ + u.bias_off;
+      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+      continue;
+    }
+    const Unit* ds = u.res_unit >= 0 ? &units[u.res_unit] : nullptr;
+    if (training) {
+      p.mode = CONV_RAW_STATS;
+      p.out0 = T(u.y);
+      p.stats = reinterpret_cast<float*>(ws + stats_off);
+      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+      if (int rc = bn_finalize_launch(p.stats, p.tiles_m, u.Cout, u.CoutPad, (long)p.M,
+                                      params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
+                                      bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
+                                      coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s))
+        return rc;
+      if (u.apply) {
+        if (int rc = bn_apply_launch(dtype, T(u.y), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3),
+                                     u.res_tensor >= 0 ? T(u.res_tensor) : nullptr,
+                                     ds ? T(ds->y) : nullptr, ds ? coef_ptr(ws, *ds, 2) : nullptr,
+                                     ds ? coef_ptr(ws, *ds, 3) : nullptr, u.relu ? 1 : 0, T(u.a),
+                                     (long)p.M, u.Cout, s))
+          return rc;
+      }
+    } else {
+      p.mode = CONV_EVAL_FUSED;
+      p.scale = coef_ptr(ws, u, 2);
+      p.shift = coef_ptr(ws, u, 3);
+      p.relu = u.relu ? 1 : 0;
+      if (u.apply) {
+        p.out0 = T(u.a);
+        p.res = u.res_tensor >= 0 ? T(u.res_tensor) : (ds ? T(ds->y) : nullptr);
+      } else {
+        p.out0 = T(u.y);  // downsample branch: bn(conv(x)) lands in its y slot
+        p.res = nullptr;
+      }
+      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+    }
+  }
+  return 0;
+}
+
+int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
+                         int seg_begin, int seg_end, hipStream_t s) const {
+  D3F_CHECK(dtype == D3F_F32, "unet backward: only f32 is implemented (dtype %d)", dtype);
+  char* ws = reinterpret_cast<char*>(ws_);
+  auto T = [&](int tid) { return ws + tensors[tid].off; };
+  auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
+  char* dy = ws + dy_off;
+  float* wpart = reinterpret_cast<float*>(ws + wpart_off);
+  for (const BwdOp& op : bwd_ops) {
+    if (op.segment < seg_begin || op.segment >= seg_end) continue;
+    if (op.kind == BW_SUM2X2) {
+      if (int rc = sum2x2_launch(dtype, ws + dfull_off, G(op.dst0), B, op.Hl, op.Wl, op.C, s)) return rc;
+      continue;
+    }
+    if (op.kind == BW_POOL) {
+      const TensorD& f1 = tensors[units[conv1].a];
+      if (int rc = maxpool3x3s2_bwd_launch(dtype, G(op.dA), reinterpret_cast<uint8_t*>(ws + pool_idx_off),
+                                           G(op.dst0), op.acc0 ? 1 : 0, B, f1.H, f1.W, f1.C, s))
+        return rc;
+      continue;
+    }
+    const Unit& u = units[op.unit];
+    const long rows = (long)B * u.Ho * u.Wo;
+    if (op.kind == BW_HEAD) {
+      if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s)) return rc;
+      if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
+                                           reinterpret_cast<float*>(ws + bsum_off), grads + u.bias_off, s))
+        return rc;
+    } else {
+      int nb = 0;
+      float* mean = coef_ptr(ws, u, 0);
+      float* invstd = coef_ptr(ws, u, 1);
+      float* k = coef_ptr(ws, u, 4);
+      float* bnpart = reinterpret_cast<float*>(ws + bnpart_off);
+      const void* amask = op.mask ? T(u.a) : nullptr;
+      if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
+                                        u.Cout, s))
+        return rc;
+      if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
+                                          grads + u.g_off, grads + u.b_off, 0, k, s))
+        return rc;
+      if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
+                                       op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
+                                       u.Cout, s))
+        return rc;
+    }
+    // weight gradient
+    WgradParams g = u.wg;
+    g.dy = dy;
+    g.src0 = T(u.in0);
+    g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
+    g.partial = wpart;
+    if (int rc = wgrad_launch(g, dtype, s)) return rc;
+    if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW,
+                                     grads + u.w_off, 0, s))
+      return rc;
+    // data gradient
+    if (u.need_dgrad) {
+      ConvParams d = u.dgrad;
+      d.src0 = dy;
+      d.w = ws + u.wd_off;
+      if (op.dst0_is_full_scratch) {
+        d.out0 = ws + dfull_off;
+        d.acc0 = 0;
+      } else {
+        d.out0 = G(op.dst0);
+        d.acc0 = op.acc0 ? 1 : 0;
+      }
+      d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
+      d.acc1 = op.acc1 ? 1 : 0;
+      if (int rc = conv_igemm_launch(d, dtype, s)) return rc;
+    }
+  }
+  return 0;
+}
+
+int UnetEngine::export_tensor(const char* name, const void* ws_, float* out_nchw, hipStream_t s) const {
+  const char* ws = reinterpret_cast<const char*>(ws_);
+  const std::string n(name);
+  const size_t colon = n.rfind(':');
+  D3F_CHECK(colon != std::string::npos, "export: name must look like '<conv>:y|a|da'");
+  const std::string un = n.substr(0, colon), kind = n.substr(colon + 1);
+  for (const Unit& u : units) {
+    if (u.conv_name != un) continue;
+    int tid = kind == "y" ? u.y : u.a;
+    D3F_CHECK(tid >= 0, "export: unit %s has no tensor '%s'", un.c_str(), kind.c_str());
+    const TensorD* t = &tensors[tid];
+    if (kind == "da") {
+      D3F_CHECK(grad_of[tid] >= 0, "export: no gradient tensor for %s", un.c_str());
+      t = &gtensors[grad_of[tid]];
+    }
+    return nhwc_to_nchw_launch(dtype, ws + t->off, out_nchw, B, t->C, t->H, t->W, t->C, s);
+  }
+  return set_error(-1, "export: no unit named %s", un.c_str());
+}
+
+}  // namespace d3f

@@ -1,0 +1,68 @@
+// HBM-bound kernels of the U-Net hot path (pointwise.hip, loss.hip, optim.hip).
+#pragma once
+#include "common.h"
+
+namespace d3f {
+
+// ---- BatchNorm, train mode (K5/K7) ------------------------------------------------------
+// stats: per-m-tile partial (sum, sumsq) written by the conv epilogue.
+// Produces mean / invstd (saved for backward), folded scale / shift, and updates the
+// running statistics (momentum, unbiased variance) like torch.nn.BatchNorm2d.
+int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long count,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t stream);
+// eval mode: scale/shift from the running statistics
+int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift,
+                         hipStream_t stream);
+// a = act(y*scale + shift + residual),  residual = res (activation) or yr*scale_r + shift_r
+int bn_apply_launch(int dtype, const void* y, const float* scale, const float* shift,
+                    const void* res, const void* yr, const float* scale_r, const float* shift_r,
+                    int relu, void* out, long rows, int C, hipStream_t stream);
+// backward: dz = dA * (a > 0 if a given);  partial sums of dz and dz*xhat
+int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
+                         const float* mean, const float* invstd, float* partial, int* nblocks,
+                         long rows, int C, hipStream_t stream);
+int bn_bwd_reduce_blocks(long rows, int C, int dtype);
+int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
+                           const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                           int accumulate, float* coef /*[3][C]*/, hipStream_t stream);
+// dy = k1*(dz - k2 - xhat*k3); optionally dz -> dres (+= if dres_acc)
+int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
+                        const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
+                        long rows, int C, hipStream_t stream);
+
+// ---- pooling / resampling / layout (K6, K8 backward, boundary) ---------------------------
+int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
+                            int C, hipStream_t stream);
+int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
+                            int B, int H, int W, int C, hipStream_t stream);
+// dlow[b,y,x,c] = sum of the 2x2 block of dfull  (backward of nearest x2 up-sampling)
+int sum2x2_launch(int dtype, const void* dfull, void* dlow, int B, int Hl, int Wl, int C,
+                  hipStream_t stream);
+// NCHW fp32 [B][C][H][W] -> NHWC T [B][H][W][Cpad] (pad channels zero) and back
+int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad,
+                        hipStream_t stream);
+int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad,
+                        hipStream_t stream);
+
+// ---- weights -------------------------------------------------------------------------------
+// PyTorch [Cout][CinReal][KH][KW] fp32 -> forward pack [CoutPad][Kpad] (k = tap*Cin + c) and/or
+// data-gradient pack [CinPadRows][KpadD] (k = flipped tap*Cout + co); T = dtype.
+int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Cin, int KH, int KW,
+                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
+                        hipStream_t stream);
+
+// ---- noise blend (K12), loss (K13), Adam (K14), EMA (K15) --------------------------------
+int noise_blend_launch(const float* x, const float* noise, const float* y_uniform, float lam,
+                       float* out, float* r_out, int B, long per_image, hipStream_t stream);
+size_t loss_workspace_floats(int B, int H, int W);
+int mse_ssim_loss_launch(const float* pred, const float* target, float in_min, float in_max,
+                         float* loss_out /*[3]: loss, mse, ssim*/, float* grad_pred, float* workspace,
+                         int B, int H, int W, hipStream_t stream);
+int adam_step_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_scale, hipStream_t stream);
+int ema_lerp_launch(float* ema, const float* online, long n, float weight, hipStream_t stream);
+
+}  // namespace d3f

@@ -1,0 +1,650 @@
+// HBM-bound kernels of the U-Net hot path: BatchNorm (train / eval, forward / backward),
+// ReLU + residual add, 3x3/s2 max-pool, 2x2 sum (backward of nearest up-sampling), layout
+// conversion at the NCHW boundary and weight packing.  All activations NHWC, every access a
+// 16-byte vector per lane, grid-stride over at most 2048 workgroups.
+//
+// These replace the ATen batch_norm / relu / add / max_pool2d / upsample_nearest2d / cat
+// kernels (forward and autograd backward) the reference's U-Net dispatches
+// (semantics: SURVEY.md Appendix A.1).
+#include "pointwise.h"
+
+namespace d3f {
+
+template <typename T> struct V16;
+template <> struct V16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct V16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+static inline int grid_for(long work_items, int per_block = 256, int cap = 2048) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ stats, int tiles, int C, int Cpad, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
+    float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lane; t < tiles; t += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * Cpad + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane == 0) {
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma[c], b = beta[c];
+    mean_o[c] = (float)mean;
+    invstd_o[c] = (float)invstd;
+    const float sc = (float)((double)g * invstd);
+    scale_o[c] = sc;
+    shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+  }
+}
+
+int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long count,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, stats, tiles, C,
+                     Cpad, (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                     invstd, scale, shift);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv,
+                                     float eps, int C, float* __restrict__ scale,
+                                     float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const T* __restrict__ res, const T* __restrict__ yr, const float* __restrict__ scale_r,
+    const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C) {
+  constexpr int N = V16<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float v[N], sc[N], sf[N];
+    V16<T>::load(y + i * N, v);
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(scale + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(shift + c0 + k);
+      sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
+      sf[k] = b.x; sf[k + 1] = b.y; sf[k + 2] = b.z; sf[k + 3] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] * sc[k] + sf[k];
+    if (res != nullptr) {
+      float r[N];
+      V16<T>::load(res + i * N, r);
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] += r[k];
+    } else if (yr != nullptr) {
+      float r[N];
+      V16<T>::load(yr + i * N, r);
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] += r[k] * scale_r[c0 + k] + shift_r[c0 + k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    V16<T>::store(out + i * N, v);
+  }
+}
+
+int bn_apply_launch(int dtype, const void* y, const float* scale, const float* shift,
+                    const void* res, const void* yr, const float* scale_r, const float* shift_r,
+                    int relu, void* out, long rows, int C, hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(C % ve == 0, "bn_apply: C=%d not a multiple of %d", C, ve);
+  const long nvec = rows * C / ve;
+  if (nvec == 0) return 0;
+  const int grid = grid_for(nvec);
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)y, scale,
+                       shift, (const float*)res, (const float*)yr, scale_r, shift_r, relu, (float*)out,
+                       nvec, C);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)y,
+                       scale, shift, (const bf16_t*)res, (const bf16_t*)yr, scale_r, shift_r, relu,
+                       (bf16_t*)out, nvec, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm backward.  dz = dA * [a > 0];  dbeta = sum dz;  dgamma = sum dz * xhat;
+// dy = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
+// ------------------------------------------------------------------------------------------
+constexpr int BN_BWD_ROWS_PER_BLOCK_MIN = 64;
+
+int bn_bwd_reduce_blocks(long rows, int C, int dtype) {
+  (void)C; (void)dtype;
+  long b = (rows + BN_BWD_ROWS_PER_BLOCK_MIN - 1) / BN_BWD_ROWS_PER_BLOCK_MIN;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
+    long rows, int C) {
+  constexpr int N = V16<T>::N;
+  __shared__ float red[256 * N * 2];
+  const int VC = C / N;        // vectors per row (power of two, <= 256)
+  const int RP = 256 / VC;     // rows per pass
+  const int cv = threadIdx.x % VC, r0 = threadIdx.x / VC;
+  const long rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const long rbeg = (long)blockIdx.x * rows_per_block;
+  long rend = rbeg + rows_per_block;
+  if (rend > rows) rend = rows;
+  float mu[N], is[N], s1[N], s2[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    mu[k] = mean[cv * N + k];
+    is[k] = invstd[cv * N + k];
+    s1[k] = 0.f;
+    s2[k] = 0.f;
+  }
+  for (long r = rbeg + r0; r < rend; r += RP) {
+    const long off = r * C + cv * N;
+    float g[N], yy[N];
+    V16<T>::load(dA + off, g);
+    V16<T>::load(y + off, yy);
+    if (a != nullptr) {
+      float aa[N];
+      V16<T>::load(a + off, aa);
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      s1[k] += g[k];
+      s2[k] += g[k] * ((yy[k] - mu[k]) * is[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    red[(threadIdx.x * N + k) * 2 + 0] = s1[k];
+    red[(threadIdx.x * N + k) * 2 + 1] = s2[k];
+  }
+  __syncthreads();
+  // thread t < 2*C sums column t over the RP row groups
+  for (int t = threadIdx.x; t < 2 * C; t += 256) {
+    const int c = t >> 1, which = t & 1;
+    const int v = c / N, k = c % N;
+    float s = 0.f;
+    for (int rr = 0; rr < RP; ++rr) s += red[((rr * VC + v) * N + k) * 2 + which];
+    partial[((long)blockIdx.x * C + c) * 2 + which] = s;
+  }
+}
+
+int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
+                         const float* mean, const float* invstd, float* partial, int* nblocks,
+                         long rows, int C, hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  const int vc = C / ve;
+  D3F_CHECK(C % ve == 0 && vc >= 1 && vc <= 256 && (256 % vc) == 0,
+            "bn_bwd_reduce: unsupported channel count %d", C);
+  const int blocks = bn_bwd_reduce_blocks(rows, C, dtype);
+  *nblocks = blocks;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream,
+                       (const float*)dA, (const float*)a, (const float*)y, mean, invstd, partial, rows, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
+                       (const bf16_t*)dA, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, partial, rows, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lane; t < nblocks; t += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * C + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane == 0) {
+    const float db = (float)s1, dg = (float)s2;
+    if (dgamma != nullptr) {
+      dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+      dbeta[c] = accumulate ? dbeta[c] + db : db;
+    }
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s1 / count);
+    coef[2 * C + c] = (float)(s2 / count);
+  }
+}
+
+int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
+                           const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                           int accumulate, float* coef, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partial, nblocks,
+                     C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+    T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C) {
+  constexpr int N = V16<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float g[N], yy[N], o[N];
+    V16<T>::load(dA + i * N, g);
+    V16<T>::load(y + i * N, yy);
+    if (a != nullptr) {
+      float aa[N];
+      V16<T>::load(a + i * N, aa);
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int c = c0 + k;
+      const float xhat = (yy[k] - mean[c]) * invstd[c];
+      o[k] = coef[c] * (g[k] - coef[C + c] - xhat * coef[2 * C + c]);
+    }
+    V16<T>::store(dy + i * N, o);
+    if (dres != nullptr) {
+      if (dres_acc) {
+        float d[N];
+        V16<T>::load(dres + i * N, d);
+#pragma unroll
+        for (int k = 0; k < N; ++k) g[k] += d[k];
+      }
+      V16<T>::store(dres + i * N, g);
+    }
+  }
+}
+
+int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
+                        const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
+                        long rows, int C, hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(C % ve == 0, "bn_bwd_apply: C=%d", C);
+  const long nvec = rows * C / ve;
+  if (nvec == 0) return 0;
+  const int grid = grid_for(nvec);
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)dA,
+                       (const float*)a, (const float*)y, mean, invstd, coef, (float*)dy, (float*)dres,
+                       dres_acc, nvec, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dA,
+                       (const bf16_t*)a, (const bf16_t*)y, mean, invstd, coef, (bf16_t*)dy, (bf16_t*)dres,
+                       dres_acc, nvec, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, padding 1): first maximum in (kh, kw) scan order wins, like ATen.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                          uint8_t* __restrict__ idx, int B, int H,
+                                                          int W, int C) {
+  constexpr int N = V16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, VC = C / N;
+  const long total = (long)B * Ho * Wo * VC;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % VC);
+    long t = i / VC;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[N];
+    int bi[N];
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[N];
+        V16<T>::load(in + (((long)b * H + iy) * W + ix) * C + cv * N, v);
+        if (first) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
+          first = false;
+        } else {
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+            if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
+        }
+      }
+    }
+    const long o = (((long)b * Ho + oy) * Wo + ox) * C + cv * N;
+    V16<T>::store(out + o, best);
+#pragma unroll
+    for (int k = 0; k < N; ++k) idx[o + k] = (uint8_t)bi[k];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout,
+                                                          const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ din, int accumulate, int B,
+                                                          int H, int W, int C) {
+  constexpr int N = V16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, VC = C / N;
+  const long total = (long)B * H * W * VC;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % VC);
+    long t = i / VC;
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H);
+    const int b = (int)(t / H);
+    float g[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) g[k] = 0.f;
+    // windows containing (iy, ix): kh = iy - (2*oy - 1) in {0,1,2}
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = iy + 1 - kh;
+      if (ty < 0 || (ty & 1)) continue;
+      const int oy = ty >> 1;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tx = ix + 1 - kw;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ox = tx >> 1;
+        if (ox >= Wo) continue;
+        const long o = (((long)b * Ho + oy) * Wo + ox) * C + cv * N;
+        float d[N];
+        V16<T>::load(dout + o, d);
+        const int tap = kh * 3 + kw;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (idx[o + k] == tap) g[k] += d[k];
+      }
+    }
+    T* dst = din + i * N;
+    if (accumulate) {
+      float old[N];
+      V16<T>::load(dst, old);
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] += old[k];
+    }
+    V16<T>::store(dst, g);
+  }
+}
+
+int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
+                            int C, hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(C % ve == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: shape (%d,%d,%d)", H, W, C);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / ve);
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)in, (float*)out, idx, B, H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const bf16_t*)in, (bf16_t*)out, idx, B, H, W, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
+                            int B, int H, int W, int C, hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(C % ve == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: shape (%d,%d,%d)", H, W, C);
+  const long total = (long)B * H * W * (C / ve);
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)dout, idx, (float*)din, accumulate, B, H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, B, H, W, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of F.interpolate(scale_factor=2, mode="nearest"): sum each 2x2 block
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sum2x2_kernel(const T* __restrict__ dfull, T* __restrict__ dlow,
+                                                     int B, int Hl, int Wl, int C) {
+  constexpr int N = V16<T>::N;
+  const int VC = C / N;
+  const long total = (long)B * Hl * Wl * VC;
+  const int Wf = 2 * Wl;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % VC);
+    long t = i / VC;
+    const int x = (int)(t % Wl);
+    t /= Wl;  // t = b*Hl + y
+    const long base = ((t * 2) * Wf + 2 * x) * (long)C + cv * N;
+    float s[N], v[N];
+    V16<T>::load(dfull + base, s);
+    V16<T>::load(dfull + base + C, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) s[k] += v[k];
+    V16<T>::load(dfull + base + (long)Wf * C, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) s[k] += v[k];
+    V16<T>::load(dfull + base + (long)Wf * C + C, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) s[k] += v[k];
+    V16<T>::store(dlow + i * N, s);
+  }
+}
+
+int sum2x2_launch(int dtype, const void* dfull, void* dlow, int B, int Hl, int Wl, int C,
+                  hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(C % ve == 0, "sum2x2: C=%d", C);
+  const long total = (long)B * Hl * Wl * (C / ve);
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(sum2x2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)dfull, (float*)dlow, B, Hl, Wl, C);
+  else
+    hipLaunchKernelGGL(sum2x2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const bf16_t*)dfull, (bf16_t*)dlow, B, Hl, Wl, C);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// boundary layout conversion
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
+                                                           T* __restrict__ out, int B, int C, long HW,
+                                                           int Cpad) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, pix = i - b * HW;
+    for (int c = 0; c < Cpad; ++c) {
+      const float v = c < C ? in[(b * C + c) * HW + pix] : 0.f;
+      out[i * Cpad + c] = from_f32<T>(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in,
+                                                           float* __restrict__ out, int B, int C,
+                                                           long HW, int Cpad) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, pix = i - b * HW;
+    for (int c = 0; c < C; ++c) out[(b * C + c) * HW + pix] = to_f32<T>(in[i * Cpad + c]);
+  }
+}
+
+int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad,
+                        hipStream_t stream) {
+  const long total = (long)B * H * W;
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, in,
+                       (float*)out, B, C, (long)H * W, Cpad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, in,
+                       (bf16_t*)out, B, C, (long)H * W, Cpad);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad,
+                        hipStream_t stream) {
+  const long total = (long)B * H * W;
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)in, out, B, C, (long)H * W, Cpad);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const bf16_t*)in, out, B, C, (long)H * W, Cpad);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (fp32 master in PyTorch layout -> kernel layouts)
+// ------------------------------------------------------------------------------------------
+// forward:  wf[n][(kh*KW + kw)*Cin + c]                     = w[n][c][kh][kw]
+// dgrad:    wd[c][((KH-1-kh)*KW + (KW-1-kw))*CoutD + n]     = w[n][c][kh][kw]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int Cout,
+                                                           int CinReal, int Cin, int KH, int KW,
+                                                           T* __restrict__ wf, int CoutPad, int Kpad,
+                                                           T* __restrict__ wd, int CinRows, int CoutD,
+                                                           int KpadD) {
+  const int taps = KH * KW;
+  const long nf = wf ? (long)CoutPad * Kpad : 0;
+  const long nd = wd ? (long)CinRows * KpadD : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (long)gridDim.x * 256) {
+    if (i < nf) {
+      const int n = (int)(i / Kpad), k = (int)(i % Kpad);
+      const int tap = k / Cin, c = k % Cin;
+      float v = 0.f;
+      if (n < Cout && tap < taps && c < CinReal) v = w[((long)n * CinReal + c) * taps + tap];
+      wf[i] = from_f32<T>(v);
+    } else {
+      const long j = i - nf;
+      const int c = (int)(j / KpadD), k = (int)(j % KpadD);
+      const int tapf = k / CoutD, n = k % CoutD;
+      float v = 0.f;
+      if (c < CinReal && tapf < taps && n < Cout) v = w[((long)n * CinReal + c) * taps + (taps - 1 - tapf)];
+      wd[j] = from_f32<T>(v);
+    }
+  }
+}
+
+int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Cin, int KH, int KW,
+                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
+                        hipStream_t stream) {
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  const int CoutD = (int)round_up(Cout, ve);
+  const long total = (wf ? (long)CoutPad * Kpad : 0) + (wd ? (long)CinRows * KpadD : 0);
+  if (total == 0) return 0;
+  D3F_CHECK(!wf || Kpad >= KH * KW * Cin, "pack: Kpad");
+  D3F_CHECK(!wd || KpadD >= KH * KW * CoutD, "pack: KpadD");
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
+                       CinReal, Cin, KH, KW, (float*)wf, CoutPad, Kpad, (float*)wd, CinRows, CoutD, KpadD);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
+                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace d3f

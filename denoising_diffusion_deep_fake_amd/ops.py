@@ -1,0 +1,175 @@
+"""Thin torch-tensor wrappers over the single-operator entry points of libd3f_hip.so.
+
+Activations are NHWC torch tensors ([B, H, W, C], C padded to 4 for f32 / 8 for bf16) that live
+on the HIP device; weights are the f32 torch-layout masters.  These wrappers exist for the
+parity tests and for callers that want one kernel at a time; the training path goes through
+`Unet` (one C call per forward / backward).  No fallbacks: every function launches a HIP kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, ptr, stream_ptr
+
+F32, BF16 = _lib.F32, _lib.BF16
+
+
+def _tdtype(dtype):
+    return torch.float32 if dtype == F32 else torch.bfloat16
+
+
+def _dev(t):
+    if t.device.type != "cuda":
+        raise _lib.D3FError("libd3f_hip ops need tensors on the HIP device (no CPU fallback)")
+    return t.device
+
+
+def make_desc(B, H, W, C0, C1, Cout, k, stride, pad, upsample0=False, cin_real=None):
+    return ConvDesc(B, H, W, C0, C1, 1 if upsample0 else 0, Cout, k, k, stride, pad,
+                    cin_real if cin_real is not None else C0 + C1)
+
+
+def out_hw(d):
+    return (d.H + 2 * d.pad - d.KH) // d.stride + 1, (d.W + 2 * d.pad - d.KW) // d.stride + 1
+
+
+def nchw_to_nhwc(x, cpad, dtype=F32):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, cpad), dtype=_tdtype(dtype), device=_dev(x))
+    check(_lib.lib().d3f_nchw_to_nhwc(dtype, ptr(x.contiguous().float()), ptr(out), B, Cc, H, W, cpad, stream_ptr()))
+    return out
+
+
+def nhwc_to_nchw(x, c, dtype=F32):
+    B, H, W, cpad = x.shape
+    out = torch.empty((B, c, H, W), dtype=torch.float32, device=_dev(x))
+    check(_lib.lib().d3f_nhwc_to_nchw(dtype, ptr(x.contiguous()), ptr(out), B, c, H, W, cpad, stream_ptr()))
+    return out
+
+
+def pack_weights(d, w, dtype=F32, dgrad=True):
+    L = _lib.lib()
+    dev = _dev(w)
+    wf = torch.empty(L.d3f_conv_packed_bytes(dtype, C.byref(d), 0), dtype=torch.uint8, device=dev)
+    wd = torch.empty(L.d3f_conv_packed_bytes(dtype, C.byref(d), 1), dtype=torch.uint8, device=dev) if dgrad else None
+    check(L.d3f_conv_pack_weights(dtype, C.byref(d), ptr(w.contiguous().float()), ptr(wf), ptr(wd), stream_ptr()))
+    return wf, wd
+
+
+def conv_forward(d, src0, src1, wf, dtype=F32, want_stats=True):
+    L = _lib.lib()
+    ho, wo = out_hw(d)
+    y = torch.empty((d.B, ho, wo, d.Cout), dtype=_tdtype(dtype), device=_dev(src0))
+    tiles = C.c_int()
+    n = L.d3f_conv_stats_floats(dtype, C.byref(d), C.byref(tiles))
+    stats = torch.zeros(n, dtype=torch.float32, device=y.device) if want_stats else None
+    check(L.d3f_conv_forward(dtype, C.byref(d), ptr(src0), ptr(src1), ptr(wf), ptr(y), ptr(stats), stream_ptr()))
+    return y, stats, tiles.value
+
+
+def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False):
+    dev = _dev(dy)
+    if dx0 is None:
+        dx0 = torch.empty((d.B, d.H, d.W, d.C0), dtype=_tdtype(dtype), device=dev)
+    if dx1 is None and d.C1 > 0:
+        dx1 = torch.empty((d.B, d.H, d.W, d.C1), dtype=_tdtype(dtype), device=dev)
+    check(_lib.lib().d3f_conv_backward_data(dtype, C.byref(d), ptr(dy), ptr(wd), ptr(dx0), ptr(dx1),
+                                            int(acc0), int(acc1), stream_ptr()))
+    return dx0, dx1
+
+
+def conv_backward_weight(d, dy, src0, src1, dtype=F32):
+    L = _lib.lib()
+    ws = torch.empty(L.d3f_conv_backward_weight_workspace_bytes(dtype, C.byref(d)), dtype=torch.uint8, device=_dev(dy))
+    dw = torch.empty((d.Cout, d.CinReal, d.KH, d.KW), dtype=torch.float32, device=dy.device)
+    check(L.d3f_conv_backward_weight(dtype, C.byref(d), ptr(dy), ptr(src0), ptr(src1), ptr(ws), ptr(dw), stream_ptr()))
+    return dw
+
+
+def bn_finalize(stats, tiles, Cc, count, gamma, beta, running_mean=None, running_var=None):
+    coef = torch.empty(4 * Cc, dtype=torch.float32, device=_dev(stats))
+    check(_lib.lib().d3f_bn_finalize(ptr(stats), tiles, Cc, count, ptr(gamma), ptr(beta), ptr(running_mean),
+                                     ptr(running_var), ptr(coef), stream_ptr()))
+    return coef
+
+
+def bn_apply(y, coef, residual=None, relu=True, dtype=F32):
+    Cc = y.shape[-1]
+    out = torch.empty_like(y)
+    check(_lib.lib().d3f_bn_apply(dtype, ptr(y), ptr(coef), Cc, y.numel() // Cc, ptr(residual), int(relu),
+                                  ptr(out), stream_ptr()))
+    return out
+
+
+def bn_backward(dA, a, y, coef, gamma, want_dres=False, dtype=F32):
+    L = _lib.lib()
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    ws = torch.empty(L.d3f_bn_backward_workspace_bytes(dtype, Cc, rows), dtype=torch.uint8, device=_dev(y))
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=y.device)
+    check(L.d3f_bn_backward(dtype, ptr(dA), ptr(a), ptr(y), ptr(coef), ptr(gamma), Cc, rows, ptr(dy), ptr(dres),
+                            ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr()))
+    return dy, dres, dgamma, dbeta
+
+
+def maxpool_forward(x, dtype=F32):
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=_dev(x))
+    idx = torch.empty((B, H // 2, W // 2, Cc), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().d3f_maxpool3x3s2_forward(dtype, ptr(x), ptr(out), ptr(idx), B, H, W, Cc, stream_ptr()))
+    return out, idx
+
+
+def maxpool_backward(dout, idx, H, W, dtype=F32, din=None):
+    B, _, _, Cc = dout.shape
+    acc = din is not None
+    if din is None:
+        din = torch.empty((B, H, W, Cc), dtype=dout.dtype, device=_dev(dout))
+    check(_lib.lib().d3f_maxpool3x3s2_backward(dtype, ptr(dout), ptr(idx), ptr(din), int(acc), B, H, W, Cc, stream_ptr()))
+    return din
+
+
+def upsample2x_backward(dfull, dtype=F32):
+    B, H, W, Cc = dfull.shape
+    out = torch.empty((B, H // 2, W // 2, Cc), dtype=dfull.dtype, device=_dev(dfull))
+    check(_lib.lib().d3f_upsample2x_backward(dtype, ptr(dfull), ptr(out), B, H // 2, W // 2, Cc, stream_ptr()))
+    return out
+
+
+def noise_blend(x, noise, y_uniform, lam, return_r=False):
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    r = torch.empty(B, dtype=torch.float32, device=_dev(x)) if return_r else None
+    check(_lib.lib().d3f_noise_blend(ptr(x), ptr(noise.contiguous().float()), ptr(y_uniform.contiguous().float()),
+                                     float(lam), ptr(out), ptr(r), B, x.numel() // max(B, 1), stream_ptr()))
+    return (out, r) if return_r else out
+
+
+def mse_ssim_loss(pred, target, in_min=-1.0, in_max=1.0):
+    """returns (loss[3] = {loss, mse, ssim} device tensor, grad wrt pred)."""
+    L = _lib.lib()
+    B, Cc, H, W = pred.shape
+    if Cc != 3:
+        raise ValueError("SSIM is defined for 3-channel images (piqa n_channels=3)")
+    pred = pred.contiguous().float()
+    target = target.contiguous().float()
+    ws = torch.empty(L.d3f_mse_ssim_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=_dev(pred))
+    out = torch.empty(3, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred)
+    check(L.d3f_mse_ssim_loss(ptr(pred), ptr(target), float(in_min), float(in_max), ptr(out), ptr(grad), ptr(ws),
+                              B, H, W, stream_ptr()))
+    return out, grad
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    check(_lib.lib().d3f_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step,
+                                   grad_scale, stream_ptr()))
+
+
+def ema_lerp(ema, online, weight):
+    check(_lib.lib().d3f_ema_lerp(ptr(ema), ptr(online), ema.numel(), float(weight), stream_ptr()))

@@ -1,0 +1,396 @@
+"""`Unet(encoder_name, encoder_weights, in_channels, classes, activation)` -- drop-in for the
+`segmentation_models_pytorch.Unet` object the reference builds at
+d3f/train_denoiser/lit_module.py:46-52 and d3f/train_deep_fake/lit_module.py:53-59.
+
+What callers rely on and what this class keeps:
+  * constructor signature and error behaviour (unknown encoder -> KeyError, H/W not divisible
+    by 32 -> RuntimeError);
+  * `__call__(Tensor[B,C,H,W] f32) -> Tensor[B,classes,H,W]`, autograd through it;
+  * `.parameters()` are ordinary leaf `nn.Parameter`s (torch.optim.Adam works on them),
+    `state_dict()` keys are smp's (`encoder.layer1.0.conv1.weight`, `decoder.blocks.0.conv1.0.weight`,
+    `segmentation_head.0.bias`, BatchNorm buffers incl. `num_batches_tracked`);
+  * `copy.deepcopy`, `.train()/.eval()/.cuda()/.to()` (EMA wrapper, video script).
+
+How it runs: every parameter is a view into ONE flat f32 buffer (likewise gradients and BN
+running statistics), and forward/backward are single calls into libd3f_hip.so's whole-network
+engine (csrc/engine.hip), which enqueues the hand-written gfx950 kernels on the current
+stream.  There is no eager / CPU fallback: tensors must live on a HIP device.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import D3FError, check, ptr, stream_ptr
+
+_DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
+           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16}
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers: same module tree (hence the same state_dict keys and initialisation)
+# as torchvision ResNet + smp UnetDecoder.  Their forward() is never used.
+# ---------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, in_channels, blocks):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inplanes = 64
+        for li, n in enumerate(blocks, start=1):
+            planes = 64 << (li - 1)
+            layers = []
+            for bi in range(n):
+                layers.append(_BasicBlock(inplanes, planes, 2 if (bi == 0 and li > 1) else 1))
+                inplanes = planes
+            setattr(self, f"layer{li}", nn.Sequential(*layers))
+        for m in self.modules():  # torchvision ResNet init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class _DecoderBlock(nn.Module):
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(cin + cskip, cout, 3, padding=1, bias=False),
+                                   nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+        self.attention1 = nn.Identity()
+        self.conv2 = nn.Sequential(nn.Conv2d(cout, cout, 3, padding=1, bias=False),
+                                   nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+        self.attention2 = nn.Identity()
+
+
+class _Decoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.center = nn.Identity()
+        spec = [(512, 256, 256), (256, 128, 128), (128, 64, 64), (64, 64, 32), (32, 0, 16)]
+        self.blocks = nn.ModuleList([_DecoderBlock(*s) for s in spec])
+        for m in self.modules():  # smp initialize_decoder
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+
+
+_ENCODERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+class _Engine:
+    """one libd3f_hip whole-network plan + its workspace, for a fixed (B, H, W, dtype)."""
+
+    def __init__(self, encoder_name, in_channels, classes, B, H, W, dtype, device):
+        L = _lib.lib()
+        self.h = C.c_void_p()
+        check(L.d3f_unet_create(encoder_name.encode(), in_channels, classes, B, H, W, dtype, C.byref(self.h)))
+        self.shape = (B, H, W)
+        self.dtype = dtype
+        self.workspace = torch.empty(L.d3f_unet_workspace_bytes(self.h), dtype=torch.uint8, device=device)
+        self.packed_version = None
+        self.fwd_flops = L.d3f_unet_forward_flops(self.h)
+        self.bwd_flops = L.d3f_unet_backward_flops(self.h)
+        self.nseg = L.d3f_unet_num_segments(self.h)
+        self.seg_ranges = []
+        for s in range(self.nseg):
+            b, e = C.c_int64(), C.c_int64()
+            check(L.d3f_unet_segment_range(self.h, s, C.byref(b), C.byref(e)))
+            self.seg_ranges.append((b.value, e.value))
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.lib().d3f_unet_destroy(self.h)
+        except Exception:
+            pass
+
+
+def param_table(encoder_name, in_channels, classes):
+    """[(name, shape, offset)] and BN table [(prefix, C, rm_off, rv_off)] from the C engine (host only)."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    check(L.d3f_unet_create(encoder_name.encode(), in_channels, classes, 1, 32, 32, _lib.F32, C.byref(h)))
+    try:
+        params, bns = [], []
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int32 * 4)()
+        nd, off = C.c_int(), C.c_int64()
+        for i in range(L.d3f_unet_num_params(h)):
+            check(L.d3f_unet_param_info(h, i, buf, 256, shape, C.byref(nd), C.byref(off)))
+            params.append((buf.value.decode(), tuple(shape[k] for k in range(nd.value)), off.value))
+        c, rm, rv = C.c_int(), C.c_int64(), C.c_int64()
+        for i in range(L.d3f_unet_num_bn(h)):
+            check(L.d3f_unet_bn_info(h, i, buf, 256, C.byref(c), C.byref(rm), C.byref(rv)))
+            bns.append((buf.value.decode(), c.value, rm.value, rv.value))
+        return params, bns, L.d3f_unet_param_floats(h), L.d3f_unet_bnstat_floats(h)
+    finally:
+        L.d3f_unet_destroy(h)
+
+
+class _UnetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, engine, *params):
+        ctx.module, ctx.engine = module, engine
+        return module._run_forward(engine, x, training=True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.module._run_backward(ctx.engine, grad_out)
+        return (None, None, None) + (None,) * len(ctx.module._param_list)
+
+
+class Unet(nn.Module):
+    def __init__(self, encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=3,
+                 activation=None, compute_dtype="f32"):
+        super().__init__()
+        if encoder_name not in _ENCODERS:
+            raise KeyError(f"Wrong encoder name `{encoder_name}`, supported encoders: {list(_ENCODERS)}")
+        if encoder_weights is not None:
+            raise KeyError(f"Wrong pretrained weights `{encoder_weights}` for encoder `{encoder_name}`. "
+                           f"Available options are: [None] (no network access)")
+        if activation is not None:
+            raise ValueError(f"Activation should be None (the reference passes activation=None); got {activation}")
+        if compute_dtype not in _DTYPES:
+            raise ValueError(f"compute_dtype must be one of f32 / bf16, got {compute_dtype}")
+        self.encoder_name, self.in_channels, self.classes = encoder_name, in_channels, classes
+        self.compute_dtype = _DTYPES[compute_dtype]
+        self.encoder = _Encoder(in_channels, _ENCODERS[encoder_name])
+        self.decoder = _Decoder()
+        self.segmentation_head = nn.Sequential(nn.Conv2d(16, classes, 3, padding=1), nn.Identity(), nn.Identity())
+        nn.init.xavier_uniform_(self.segmentation_head[0].weight)
+        nn.init.constant_(self.segmentation_head[0].bias, 0)
+        self._init_runtime_state()
+
+    # -- runtime state that must not be deep-copied / pickled ------------------------------------
+    def _init_runtime_state(self):
+        self.__dict__["_rt"] = {"flat": None, "flat_grad": None, "flat_bn": None, "flat_nbt": None,
+                                "engines": {}, "table": None, "dirty": True, "grad_sync": None, "params": None}
+
+    def __deepcopy__(self, memo):
+        rt = self.__dict__.pop("_rt")
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            import copy
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+            new._init_runtime_state()
+        finally:
+            self.__dict__["_rt"] = rt
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_rt", None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._init_runtime_state()
+
+    # -- flat buffers -----------------------------------------------------------------------------
+    def _table(self):
+        rt = self._rt
+        if rt["table"] is None:
+            rt["table"] = param_table(self.encoder_name, self.in_channels, self.classes)
+            names = [n for n, _ in self.named_parameters()]
+            tnames = [n for n, _, _ in rt["table"][0]]
+            if names != tnames:
+                raise D3FError("parameter order of the module tree and of the C engine differ")
+        return rt["table"]
+
+    @property
+    def _param_list(self):
+        rt = self._rt
+        if rt.get("params") is None:
+            rt["params"] = [p for _, p in self.named_parameters()]
+        return rt["params"]
+
+    def _ensure_flat(self, device):
+        """(re)establish: every parameter / BN buffer is a view into the flat device buffers."""
+        rt = self._rt
+        ptable, btable, nparam, nbn = self._table()
+        named = dict(self.named_parameters())
+        flat = rt["flat"]
+        ok = flat is not None and flat.device == device
+        if ok:
+            base = flat.data_ptr()
+            for name, shape, off in ptable:
+                p = named[name]
+                if p.data_ptr() != base + 4 * off or p.device != device:
+                    ok = False
+                    break
+        if ok:
+            bufs = dict(self.named_buffers())
+            bb = rt["flat_bn"].data_ptr()
+            for prefix, c, rm, rv in btable:
+                if bufs[prefix + ".running_mean"].data_ptr() != bb + 4 * rm:
+                    ok = False
+                    break
+        if ok:
+            return
+        flat = torch.empty(nparam, dtype=torch.float32, device=device)
+        flat_bn = torch.empty(nbn, dtype=torch.float32, device=device)
+        flat_nbt = torch.zeros(len(btable), dtype=torch.int64, device=device)
+        with torch.no_grad():
+            for name, shape, off in ptable:
+                p = named[name]
+                if tuple(p.shape) != tuple(shape):
+                    raise D3FError(f"parameter {name}: shape {tuple(p.shape)} != engine {shape}")
+                view = flat[off:off + p.numel()].view(shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+            mods = dict(self.named_modules())
+            for i, (prefix, c, rm, rv) in enumerate(btable):
+                bn = mods[prefix]
+                for attr, o in (("running_mean", rm), ("running_var", rv)):
+                    view = flat_bn[o:o + c]
+                    view.copy_(getattr(bn, attr).to(device=device, dtype=torch.float32))
+                    setattr(bn, attr, view)
+                flat_nbt[i] = bn.num_batches_tracked.to(device)
+                bn.num_batches_tracked = flat_nbt[i]
+        rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, dirty=True,
+                  params=[named[name] for name, _, _ in ptable])
+        for p in named.values():
+            p.grad = None
+
+    def mark_params_changed(self):
+        """call after writing the flat parameter buffer behind autograd's back (fused Adam / EMA)."""
+        self._rt["dirty"] = True
+
+    @property
+    def flat_params(self):
+        return self._rt["flat"]
+
+    @property
+    def flat_grads(self):
+        return self._rt["flat_grad"]
+
+    @property
+    def flat_bn_stats(self):
+        return self._rt["flat_bn"]
+
+    def prepare(self, device=None):
+        """flatten parameters now (otherwise done lazily by the first forward); returns self."""
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        if device.type != "cuda":
+            raise D3FError("d3f Unet runs on an MI355X (HIP) device only; there is no CPU fallback")
+        self._ensure_flat(device)
+        return self
+
+    def set_grad_sync(self, fn):
+        """fn(segment_index, flat_grad_slice) is called as soon as a gradient bucket is final
+        (data-parallel all-reduce overlap); None disables."""
+        self._rt["grad_sync"] = fn
+
+    # -- engine -------------------------------------------------------------------------------------
+    def _engine(self, B, H, W, device):
+        key = (B, H, W, self.compute_dtype, device.index)
+        eng = self._rt["engines"].get(key)
+        if eng is None:
+            eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device)
+            self._rt["engines"][key] = eng
+        return eng
+
+    def _pack_if_needed(self, eng):
+        rt = self._rt
+        # `p.data = view` keeps every parameter's OWN version counter, so in-place updates by
+        # torch optimizers / load_state_dict show up on the parameters, not on the flat buffer
+        ver = sum(p._version for p in rt["params"]) + rt["flat"]._version
+        if rt["dirty"]:
+            for e in rt["engines"].values():
+                e.packed_version = None
+            rt["dirty"] = False
+        if eng.packed_version != ver:
+            check(_lib.lib().d3f_unet_pack_weights(eng.h, ptr(rt["flat"]), ptr(eng.workspace), stream_ptr()))
+            eng.packed_version = ver
+
+    def _run_forward(self, eng, x, training):
+        rt = self._rt
+        self._pack_if_needed(eng)
+        out = torch.empty((x.shape[0], self.classes, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        check(_lib.lib().d3f_unet_forward(eng.h, ptr(rt["flat"]), ptr(rt["flat_bn"]), ptr(x), ptr(out),
+                                          ptr(eng.workspace), 1 if training else 0, stream_ptr()))
+        if training:
+            rt["flat_nbt"] += 1
+        return out
+
+    def _run_backward(self, eng, grad_out):
+        rt = self._rt
+        L = _lib.lib()
+        grad_out = grad_out.contiguous().float()
+        params = self._param_list
+        direct = all(p.grad is None for p in params)
+        if rt["flat_grad"] is None:
+            rt["flat_grad"] = torch.empty_like(rt["flat"])
+        target = rt["flat_grad"] if direct else torch.empty_like(rt["flat"])
+        sync = rt["grad_sync"]
+        if sync is None:
+            check(L.d3f_unet_backward(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target), ptr(eng.workspace),
+                                      0, eng.nseg, stream_ptr()))
+        else:
+            for s in range(eng.nseg):
+                check(L.d3f_unet_backward(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target),
+                                          ptr(eng.workspace), s, s + 1, stream_ptr()))
+                b, e = eng.seg_ranges[s]
+                sync(s, target[b:e])
+        ptable = self._table()[0]
+        for (name, shape, off), p in zip(ptable, params):
+            if not p.requires_grad:
+                continue
+            view = target[off:off + p.numel()].view(shape)
+            if p.grad is None:
+                p.grad = view if direct else view.clone()
+            else:
+                p.grad.add_(view)
+
+    # -- nn.Module API ------------------------------------------------------------------------------
+    def check_input_shape(self, x):
+        h, w = x.shape[-2:]
+        if h % 32 != 0 or w % 32 != 0:
+            new_h = (h // 32 + 1) * 32 if h % 32 != 0 else h
+            new_w = (w // 32 + 1) * 32 if w % 32 != 0 else w
+            raise RuntimeError(
+                f"Wrong input shape height={h}, width={w}. Expected image height and width divisible by 32. "
+                f"Consider pad your images to shape ({new_h}, {new_w}).")
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"Expected input [B, {self.in_channels}, H, W], got {list(x.shape)}")
+        self.check_input_shape(x)
+        if x.device.type != "cuda":
+            raise D3FError("d3f Unet runs on an MI355X (HIP) device only; there is no CPU fallback "
+                           "(input tensor is on %s)" % x.device)
+        self._ensure_flat(x.device)
+        xin = x.detach().contiguous().float()
+        eng = self._engine(x.shape[0], x.shape[2], x.shape[3], x.device)
+        params = self._param_list
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad:
+            if not self.training:
+                raise D3FError("backward through an eval-mode Unet is not supported (BatchNorm is folded)")
+            if x.requires_grad:
+                raise D3FError("gradient w.r.t. the network input is not computed by the HIP path")
+            return _UnetFunction.apply(xin, self, eng, *params)
+        return self._run_forward(eng, xin, training=self.training)
+
+    # flops of the conv contractions of one call (2*MAC), for roofline reporting
+    def conv_flops(self, B, H, W, device="cuda"):
+        eng = self._engine(B, H, W, torch.device(device, torch.cuda.current_device()))
+        return eng.fwd_flops, eng.bwd_flops

@@ -1,0 +1,161 @@
+/* libd3f_hip.so -- C ABI of the MI355X-native U-Net hot path of d3f
+ * (ChainBreak/denoising_diffusion_deep_fake).
+ *
+ * The reference is pure Python on PyTorch: its "FFI" for this path is the torch op
+ * dispatch under `segmentation_models_pytorch.Unet(...)`, `MseStructuralSimilarityLoss`,
+ * `torch.optim.Adam` and `ema_pytorch.EMA`.  Each entry point below names the reference
+ * call site (file:line under /root/reference) whose device work it replaces.  The Python
+ * binding a maintainer adds is a ctypes stub: see INTEGRATION.md and
+ * denoising_diffusion_deep_fake_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; d3f_last_error() gives the
+ *     thread-local message.
+ *   - all pointers are DEVICE pointers borrowed for the duration of the call (memory is
+ *     owned by the caller, i.e. PyTorch's allocator); nothing is allocated or freed on the
+ *     device by this library.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     Calls only enqueue work; they never synchronise.
+ *   - dtype: 0 = f32, 1 = bf16 (activations / packed weights; master params are f32).
+ *   - network boundary tensors are NCHW f32 (what the reference's callers hold);
+ *     internal activations are NHWC with channels padded to a 16-byte multiple.
+ */
+#ifndef D3F_HIP_H
+#define D3F_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3F_F32 0
+#define D3F_BF16 1
+
+int d3f_version(void);
+const char* d3f_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Whole-network handle: Unet(encoder_name, encoder_weights=None, in_channels, classes,
+ * activation=None) for a fixed (B, H, W, dtype).
+ * Replaces: model construction  d3f/train_denoiser/lit_module.py:41-53,
+ *                               d3f/train_deep_fake/lit_module.py:49-60
+ *           forward             d3f/train_denoiser/lit_module.py:117 (self.model(image_noisy)),
+ *                               d3f/train_deep_fake/lit_module.py:173,189,195,266
+ *           backward            Lightning's loss.backward() on that module
+ * ------------------------------------------------------------------------------------- */
+typedef struct d3f_unet* d3f_unet_t;
+
+int d3f_unet_create(const char* encoder_name, int in_channels, int classes, int B, int H, int W,
+                    int dtype, d3f_unet_t* out);
+int d3f_unet_destroy(d3f_unet_t h);
+
+/* parameter table, in torch named_parameters() order; offsets are in floats into ONE flat
+ * f32 buffer that holds every parameter (gradients use the same layout). */
+int d3f_unet_num_params(d3f_unet_t h);
+int d3f_unet_param_info(d3f_unet_t h, int i, char* name, int name_cap, int32_t shape[4], int* ndim,
+                        int64_t* offset);
+int64_t d3f_unet_param_floats(d3f_unet_t h);
+/* BatchNorm running statistics: flat f32 buffer, per layer running_mean[C] then running_var[C] */
+int d3f_unet_num_bn(d3f_unet_t h);
+int d3f_unet_bn_info(d3f_unet_t h, int i, char* prefix, int prefix_cap, int* C, int64_t* rm_offset,
+                     int64_t* rv_offset);
+int64_t d3f_unet_bnstat_floats(d3f_unet_t h);
+size_t d3f_unet_workspace_bytes(d3f_unet_t h);
+/* algorithmic conv FLOPs (2*MAC, unpadded channels) of one forward / one backward call */
+double d3f_unet_forward_flops(d3f_unet_t h);
+double d3f_unet_backward_flops(d3f_unet_t h);
+
+/* re-pack the f32 master weights into the kernels' layouts (call after every parameter update) */
+int d3f_unet_pack_weights(d3f_unet_t h, const float* params, void* workspace, void* stream);
+/* x, out: NCHW f32 [B][in_channels|classes][H][W].  training != 0: BatchNorm uses batch statistics,
+ * updates bnstats (momentum 0.1) and keeps what backward needs in the workspace. */
+int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
+                     void* workspace, int training, void* stream);
+/* gradients of every parameter (written, not accumulated) for the preceding training forward.
+ * The backward pass is cut into d3f_unet_num_segments() buckets so a data-parallel caller can
+ * all-reduce bucket k while bucket k+1 computes: run segments [seg_begin, seg_end) in order 0..n;
+ * after segment k, grads[begin_k, end_k) (floats) are final. */
+int d3f_unet_num_segments(d3f_unet_t h);
+int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end);
+int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
+                      void* workspace, int seg_begin, int seg_end, void* stream);
+/* debugging / tests: copy an internal activation ("<conv name>:y" raw conv output, ":a" post
+ * BN+ReLU, ":da" its gradient) to NCHW f32 */
+int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Single operators (the kernels the network is made of; used by the parity tests)
+ * ------------------------------------------------------------------------------------- */
+typedef struct d3f_conv_desc {
+  int32_t B, H, W;    /* extent of the conv input (after the optional x2 up-sampling of src0) */
+  int32_t C0, C1;     /* channels of src0 and of the concatenated src1 (0: none); padded to 4 (f32) / 8 (bf16) */
+  int32_t upsample0;  /* 1: src0 is [B][H/2][W/2][C0], read through nearest x2 up-sampling */
+  int32_t Cout, KH, KW, stride, pad;
+  int32_t CinReal;    /* unpadded input channels of the f32 master weight [Cout][CinReal][KH][KW] */
+} d3f_conv_desc;
+
+/* torch.nn.Conv2d weight -> packed forward (which=0) / data-gradient (which=1) operand */
+size_t d3f_conv_packed_bytes(int dtype, const d3f_conv_desc* d, int which);
+int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
+                          void* stream);
+/* y = conv(cat(up(src0), src1)) NHWC; stats != NULL: per-channel (sum, sumsq) partials for
+ * d3f_bn_finalize, d3f_conv_stats_floats() floats.  Replaces F.interpolate + torch.cat + conv2d
+ * of smp's DecoderBlock / torchvision BasicBlock under lit_module.py:117. */
+size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int* tiles);
+int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
+                     const void* w_fwd, void* y, float* stats, void* stream);
+/* dx over the conv input: channels [0,C0) -> dx0 (full resolution even when upsample0),
+ * [C0,C0+C1) -> dx1; acc*: add to the destination instead of overwriting */
+int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
+                           void* dx0, void* dx1, int acc0, int acc1, void* stream);
+/* dw in torch layout [Cout][CinReal][KH][KW] f32 */
+size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d);
+int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, const void* src0,
+                             const void* src1, void* workspace, float* dw, void* stream);
+
+/* BatchNorm2d, train mode (eps 1e-5, momentum 0.1): finalize conv statistics, then
+ * a = relu?(y*scale + shift + residual); coef = mean[C] invstd[C] scale[C] shift[C] */
+int d3f_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float* coef, void* stream);
+int d3f_bn_apply(int dtype, const void* y, const float* coef, int C, int64_t rows, const void* residual,
+                 int relu, void* out, void* stream);
+/* backward of a = relu?(bn(y) + residual): dy, dgamma, dbeta, and (dres != NULL) dz for the residual */
+size_t d3f_bn_backward_workspace_bytes(int dtype, int C, int64_t rows);
+int d3f_bn_backward(int dtype, const void* dA, const void* a_or_null, const void* y, const float* coef,
+                    const float* gamma, int C, int64_t rows, void* dy, void* dres, float* dgamma,
+                    float* dbeta, void* workspace, void* stream);
+
+int d3f_maxpool3x3s2_forward(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int d3f_maxpool3x3s2_backward(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
+                              int B, int H, int W, int C, void* stream);
+int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int Hlow, int Wlow, int C, void* stream);
+int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream);
+int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training-step arithmetic around the network
+ * ------------------------------------------------------------------------------------- */
+/* blend_random_amount_of_noise_with_each_sample + sample_random_number_from_exponential_distribution
+ * (d3f/train_denoiser/lit_module.py:128-153 == d3f/train_deep_fake/lit_module.py:208-233) given the
+ * caller's draws noise ~ N(0,1) [B][per_image] and y ~ U[0,1) [B]:
+ *   r = (1/lam) * log(1 / (y*(1-c) + c)), c = exp(-lam);  out = sqrt(1-r)*x + sqrt(r)*noise */
+int d3f_noise_blend(const float* x, const float* noise, const float* y_uniform, float lam, float* out,
+                    float* r_out_or_null, int B, int64_t per_image, void* stream);
+/* MseStructuralSimilarityLoss(input_min, input_max)(prediction, target)
+ * (d3f/loss_functions/structural_similarity_loss.py:14-26; piqa.SSIM defaults) on NCHW f32
+ * [B][3][H][W]: loss_out = {loss, mse, ssim}; grad_pred = d loss / d prediction. */
+size_t d3f_mse_ssim_loss_workspace_bytes(int B, int H, int W);
+int d3f_mse_ssim_loss(const float* pred, const float* target, float input_min, float input_max,
+                      float* loss_out, float* grad_pred, void* workspace, int B, int H, int W, void* stream);
+/* torch.optim.Adam step over a flat buffer (lit_module.py:95 / train_deep_fake/lit_module.py:116-120);
+ * step counts from 1; grad_scale multiplies the gradient first (1/world_size for data parallel) */
+int d3f_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* ema.lerp_(online, weight)  (ema_pytorch update used at d3f/train_deep_fake/lit_module.py:185) */
+int d3f_ema_lerp(float* ema, const float* online, int64_t n, float weight, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3F_HIP_H */

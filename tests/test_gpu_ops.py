@@ -1,0 +1,252 @@
+"""GPU parity of the single HIP operators (through the C ABI) against plain fp32 PyTorch on CPU.
+
+Tolerances (fp32 path): the MFMA f32 instructions are exact-f32 fmaf chains, so differences come
+only from summation order: rel-L2 <= 1e-5 for contractions, <= 1e-6 for pointwise kernels.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import max_rel, rel_l2, to_nchw, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+TOL_CONV = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from denoising_diffusion_deep_fake_amd import ops as o
+    return o
+
+
+def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=None, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    cin = C0 + C1
+    cr = cin_real or cin
+    h0, w0 = (H // 2, W // 2) if up else (H, W)
+    x0 = torch.randn(B, C0 if C1 or not cin_real else cr, h0, w0, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, cr, k, k, generator=g) / (cr * k * k) ** 0.5
+    # ---- reference -------------------------------------------------------------------------
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up else x0
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+    xin = xin.requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xin, wr, None, stride, pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    # ---- HIP -------------------------------------------------------------------------------
+    d = ops.make_desc(B, H, W, C0, C1, Cout, k, stride, pad, up, cr)
+    s0 = to_nhwc(x0, C0).cuda()
+    s1 = to_nhwc(x1).cuda() if x1 is not None else None
+    wf, wd = ops.pack_weights(d, w.cuda())
+    y, stats, tiles = ops.conv_forward(d, s0, s1, wf)
+    torch.cuda.synchronize()
+    y_h = to_nchw(y.cpu())
+    assert rel_l2(y_h, y_ref) < TOL_CONV, ("fwd", rel_l2(y_h, y_ref))
+    # statistics partials: per-channel sum / sumsq of the conv output
+    cpad = (Cout + 15) // 16 * 16
+    st = stats.view(tiles, cpad, 2).double().sum(0).cpu()
+    ref_s1 = y_ref.detach().double().sum((0, 2, 3))
+    ref_s2 = (y_ref.detach().double() ** 2).sum((0, 2, 3))
+    assert max_rel(st[:Cout, 1], ref_s2) < 1e-5
+    assert (st[:Cout, 0] - ref_s1).abs().max() < 1e-3 * (1 + ref_s2.sqrt().max())
+    # weight gradient
+    co_pad = (Cout + 3) // 4 * 4
+    dy_h = to_nhwc(dy, co_pad).cuda()
+    dw = ops.conv_backward_weight(d, dy_h, s0, s1)
+    assert rel_l2(dw.cpu(), wr.grad) < TOL_CONV, ("wgrad", rel_l2(dw.cpu(), wr.grad))
+    # data gradient (the padded first conv never needs one)
+    if cin_real is None:
+        dx0, dx1 = ops.conv_backward_data(d, dy_h, wd)
+        dxr = xin.grad
+        assert rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]) < TOL_CONV, ("dgrad0", rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]))
+        if C1:
+            assert rel_l2(to_nchw(dx1.cpu()), dxr[:, C0:]) < TOL_CONV
+        if up:
+            low = ops.upsample2x_backward(dx0)
+            # autograd reference of the up-sampling
+            x0r = x0.clone().requires_grad_(True)
+            F.interpolate(x0r, scale_factor=2, mode="nearest").backward(dxr[:, :C0])
+            assert rel_l2(to_nchw(low.cpu()), x0r.grad) < 1e-6
+        # accumulate flag
+        base = torch.randn(dx0.shape, generator=g).cuda()
+        acc, _ = ops.conv_backward_data(d, dy_h, wd, dx0=base.clone(), dx1=dx1, acc0=True)
+        assert rel_l2(acc.cpu(), (base + dx0).cpu()) < 1e-6
+
+
+CASES = [
+    # B, H, W, C0, C1, Cout, k, stride, pad, up
+    (2, 16, 16, 64, 0, 64, 3, 1, 1, False),      # layer1 block conv (64x64 tile)
+    (2, 16, 16, 64, 0, 128, 3, 2, 1, False),     # stride-2 block entry
+    (2, 16, 16, 64, 0, 128, 1, 2, 0, False),     # 1x1 stride-2 downsample
+    (3, 10, 10, 32, 0, 64, 3, 1, 1, False),      # ragged M (300 rows)
+    (1, 8, 8, 256, 0, 256, 3, 1, 1, False),      # deep layer, long K
+    (2, 16, 16, 64, 64, 32, 3, 1, 1, True),      # decoder: upsample + concat -> 32 (256x32 tile)
+    (2, 16, 16, 32, 0, 16, 3, 1, 1, True),       # decoder block 4 conv1 (256x16 tile, 16x16 MFMA)
+    (2, 16, 16, 16, 0, 16, 3, 1, 1, False),      # small-channel K path
+    (1, 32, 32, 128, 64, 64, 3, 1, 1, True),     # decoder block 2
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    _conv_case(ops, *case)
+
+
+def test_conv_first_layer_7x7(ops):
+    # encoder.conv1: 3 real input channels padded to 4, 7x7 stride 2
+    _conv_case(ops, 2, 32, 32, 4, 0, 64, 7, 2, 3, False, cin_real=3)
+
+
+def test_conv_large_tiles(ops):
+    # enough rows for the 128x128 and 128x64 tile configurations
+    _conv_case(ops, 4, 128, 128, 32, 0, 128, 3, 1, 1, False)
+    _conv_case(ops, 4, 128, 128, 32, 0, 64, 3, 1, 1, False, seed=1)
+
+
+def test_batchnorm_train_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 4, 64, 12, 12
+    x = torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(C, 32, 3, 3, generator=g) * 0.1
+    res = torch.randn(B, C, H, W, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    wr = w.clone()
+    y_ref = F.conv2d(x, wr, None, 1, 1).requires_grad_(True)
+    resr = res.clone().requires_grad_(True)
+    a_ref = F.relu(bn(y_ref) + resr)
+    dA = torch.randn(a_ref.shape, generator=g)
+    a_ref.backward(dA)
+
+    d = ops.make_desc(B, H, W, 32, 0, C, 3, 1, 1)
+    wf, _ = ops.pack_weights(d, w.cuda(), dgrad=False)
+    y, stats, tiles = ops.conv_forward(d, to_nhwc(x).cuda(), None, wf)
+    rm = torch.zeros(C).cuda()
+    rv = torch.ones(C).cuda()
+    coef = ops.bn_finalize(stats, tiles, C, B * H * W, gamma.cuda(), beta.cuda(), rm, rv)
+    a = ops.bn_apply(y, coef, residual=to_nhwc(res).cuda(), relu=True)
+    assert rel_l2(to_nchw(a.cpu()), a_ref) < 1e-5
+    assert rel_l2(rm.cpu(), bn.running_mean) < 1e-5
+    assert rel_l2(rv.cpu(), bn.running_var) < 1e-5
+    dy, dres, dgamma, dbeta = ops.bn_backward(to_nhwc(dA).cuda(), a, y, coef, gamma.cuda(), want_dres=True)
+    assert rel_l2(to_nchw(dy.cpu()), y_ref.grad) < 2e-5
+    assert rel_l2(to_nchw(dres.cpu()), resr.grad) < 1e-6
+    assert rel_l2(dgamma.cpu(), bn.weight.grad) < 2e-5
+    assert rel_l2(dbeta.cpu(), bn.bias.grad) < 2e-5
+
+
+def test_maxpool_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(4)
+    x = F.relu(torch.randn(2, 8, 12, 16, generator=g))  # post-ReLU: many exact ties at 0
+    x[0, 0, 2:5, 2:5] = 1.25                               # exact positive ties too
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    out, idx = ops.maxpool_forward(to_nhwc(x).cuda())
+    assert torch.equal(to_nchw(out.cpu()), y_ref.detach())
+    din = ops.maxpool_backward(to_nhwc(dy).cuda(), idx, 12, 16)
+    # ATen's tie order (first maximum in scan order) is reproduced; a mis-routed tie would be an
+    # O(1) error.  Overlapping windows add in a different order -> float tolerance, not bitwise.
+    torch.testing.assert_close(to_nchw(din.cpu()), xr.grad, rtol=1e-6, atol=1e-6)
+    base = torch.ones_like(din)
+    acc = ops.maxpool_backward(to_nhwc(dy).cuda(), idx, 12, 16, din=base.clone())
+    torch.testing.assert_close(acc.cpu(), (base + din).cpu())
+
+
+def test_noise_blend_matches_golden(ops, golden_dir):
+    g = np.load(golden_dir / "blend.npz")
+    x = torch.from_numpy(g["x"])
+    # sampler: r from the reference's uniform draws (logf differs from libm by <= 2 ulp)
+    y = torch.from_numpy(g["sampler_y"]).reshape(-1)
+    xs = torch.zeros(16, 4)
+    _, r = ops.noise_blend(xs.cuda(), xs.cuda(), y.cuda(), 5.0, return_r=True)
+    np.testing.assert_allclose(r.cpu().numpy(), g["sampler_r_lam5"].reshape(-1), rtol=3e-6, atol=1e-9)
+    # blend given the reference's noise: recover y from r is not possible, so check via the oracle
+    # formula on device draws instead, and the golden outputs through explicit (noise, r)
+    import oracle
+    for lam in (3, 5, 8):
+        torch.manual_seed(0)
+        yy = torch.rand(4)
+        noise = torch.from_numpy(g[f"denoiser_lam{lam}_seed0_noise"])
+        out, r = ops.noise_blend(x.cuda(), noise.cuda(), yy.cuda(), float(lam), return_r=True)
+        c = 1 / np.exp(lam)
+        r_ref = 1 / lam * torch.log(1 / (yy * (1 - c) + c))
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref.numpy(), rtol=3e-6)
+        ref = oracle.step_oracle.blend_with_given_noise(x, noise, r.cpu())
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_mse_ssim_loss_fwd_bwd(ops, golden_dir):
+    import oracle
+    g = torch.Generator().manual_seed(7)
+    for (B, H, W) in [(2, 32, 32), (1, 64, 96), (3, 40, 33)]:
+        t = oracle.synthetic_face_crops(B, 64, seed=5)[:, :, :H, :W].contiguous()
+        p = (t + 0.3 * torch.randn(t.shape, generator=g)).clone()
+        p[0, 0, :4, :4] = 1.7   # outside [-1,1]: exercises the clip and its zero gradient
+        p[0, 1, 5, 5] = -1.0    # exactly on the clip boundary (gradient passes, like torch)
+        pr = p.clone().requires_grad_(True)
+        p64 = p.double().requires_grad_(True)
+        crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+        loss_ref = crit(pr, t)
+        loss_ref.backward()
+        loss64 = crit(p64, t.double())
+        loss64.backward()
+        out, grad = ops.mse_ssim_loss(p.cuda(), t.cuda())
+        out = out.cpu()
+        assert abs(out[0].item() - loss64.item()) < 2e-6
+        assert abs(out[1].item() - F.mse_loss(p, t).item()) < 1e-6
+        # sigma = E[x^2] - mu^2 cancels in fp32: the gradient's fp32 noise floor is ~1e-5.  Stated
+        # tolerance: rel-L2 5e-5 vs the float64 evaluation, and within 4x the CPU-fp32 oracle's own error
+        e_hip, e_cpu = rel_l2(grad.cpu(), p64.grad), rel_l2(pr.grad, p64.grad)
+        assert e_hip < 5e-5 and e_hip < max(4 * e_cpu, 5e-6), (e_hip, e_cpu)
+    # first-party combination formula against the reference golden (ssim term = ours)
+    gl = np.load(golden_dir / "loss_first_party.npz")
+    p, t = torch.from_numpy(gl["pred"]), torch.from_numpy(gl["target"])
+    out, _ = ops.mse_ssim_loss(p.cuda(), t.cuda())
+    out = out.cpu()
+    # golden: loss computed by the reference with ssim := 0.25  ->  (mse + 0.75)/2
+    mse_from_golden = 2 * float(gl["loss_with_ssim_0.25"]) - 0.75
+    assert abs(out[1].item() - mse_from_golden) < 1e-6
+    assert abs(out[0].item() - (out[1].item() + 1 - out[2].item()) / 2) < 1e-7
+
+
+def test_adam_and_ema(ops):
+    g = torch.Generator().manual_seed(9)
+    n = 1003  # not a multiple of 4: exercises the tail
+    p = torch.randn(n, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=0.02, betas=(0.5, 0.999))
+    ph = p.clone().cuda()
+    m = torch.zeros(n).cuda()
+    v = torch.zeros(n).cuda()
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g)
+        pr.grad = grad.clone()
+        opt.step()
+        ops.adam_step(ph, grad.cuda(), m, v, 0.02, 0.5, 0.999, 1e-8, step)
+        assert max_rel(ph.cpu(), pr.detach()) < 2e-6
+    a = torch.randn(n, generator=g)
+    b = torch.randn(n, generator=g)
+    for w in (0.3, 1 - 0.9999, 0.75):
+        e = a.clone().cuda()
+        ops.ema_lerp(e, b.cuda(), w)
+        torch.testing.assert_close(e.cpu(), torch.lerp(a, b, w), rtol=1e-6, atol=1e-7)
+
+
+def test_layout_roundtrip(ops):
+    x = torch.randn(2, 3, 8, 10)
+    h = ops.nchw_to_nhwc(x.cuda(), 4)
+    assert h.shape == (2, 8, 10, 4) and torch.equal(h[..., 3].cpu(), torch.zeros(2, 8, 10))
+    assert torch.equal(ops.nhwc_to_nchw(h, 3).cpu(), x)
