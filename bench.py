@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the d3f noisy->clean training step (noise blend ->
+U-Net forward -> (MSE + 1-SSIM)/2 -> backward -> Adam) on synthetic 256x256 face crops, bs=16 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+one rank per GPU over RCCL.)  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_START = time.perf_counter()
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket the contraction kernels with HIP events in the timed region")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(size, batch, steps):
+    """the CPU oracle (pure torch.nn restatement, oracle/) timed on this box's host cores."""
+    import oracle
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads (affinity {len(os.sched_getaffinity(0))})")
+    torch.manual_seed(0)
+    model = oracle.Unet("resnet34", None, 3, 3, None).train()
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    opt = torch.optim.Adam(model.parameters(), lr=0.02)
+    x = oracle.synthetic_face_crops(batch, size, seed=1234)
+    g = torch.Generator().manual_seed(1)
+    noise = torch.randn(x.shape, generator=g)
+    r = torch.rand(batch, generator=g) * 0.5 + 0.05
+    t0 = time.perf_counter()
+    oracle.training_step(model, crit, opt, x, noise, r)  # warm-up
+    log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f}s")
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(steps):
+        oracle.training_step(model, crit, opt, x, noise, r)
+        done += 1
+        log(f"cpu baseline: step {done}/{steps}")
+        if time.perf_counter() - t0 > 45.0:  # bounded sample
+            break
+    steps = done
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps (after 1 warm-up) of the oracle at bs={batch}, {size}x{size}, fp32, "
+                      f"torch.set_num_threads({cores})"}
+
+
+def main():
+    args = parse()
+    from denoising_diffusion_deep_fake_amd import _lib
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.distributed import DataParallel, init_process_group
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    import ctypes as C
+    import torch.distributed as dist
+
+    world, rank, local = init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)  # identical init on every rank (and broadcast from rank 0 anyway)
+    lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
+                    num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
+                    mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
+                    augment=False, precision=args.dtype).to(dev).train()
+    (opt,), _ = lit.configure_optimizers()
+    DataParallel(lit.model, opt)
+    torch.manual_seed(1000 + rank)  # distinct noise stream per rank
+    nb = 4  # resident synthetic batches, distinct per rank
+    data = [synthetic_face_crops(args.batch, args.size, seed=1234 + 97 * rank + i, device=dev) for i in range(nb)]
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = lit.training_step({"image": data[i % nb], "index": None}, i)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = _lib.lib()
+    log("model built, starting warm-up")
+    for i in range(args.warmup):
+        loss = step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    use_events = not args.no_kernel_events
+    fence()
+    if use_events:
+        _lib.check(L.d3f_profile_enable(args.steps * 160 + 64))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+    ms, n, fl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+    if use_events:
+        L.d3f_profile_collect(ms, n, fl)
+        L.d3f_profile_enable(0)
+    lossv = float(loss.item())
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if not (lossv == lossv) or abs(lossv) > 1e6:
+        raise SystemExit(f"non-finite loss {lossv}")
+
+    images = args.batch * args.steps * world
+    fwd_fl, bwd_fl = lit.model.conv_flops(args.batch, args.size, args.size, dev)
+    step_flops = fwd_fl + bwd_fl
+    out = {
+        "metric": "training images/sec (256x256 U-Net, bs=16/GPU)",
+        "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"d3f train_denoiser step: noise blend -> Unet(resnet34) fwd -> (MSE+1-SSIM)/2 -> bwd "
+                               f"-> Adam, {args.size}x{args.size} synthetic face crops, bs={args.batch}/GPU, "
+                               f"random-init weights, train-mode BatchNorm",
+                   "image_size": args.size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "final_loss": round(lossv, 5),
+                   "conv_gflop_per_image_step": round(step_flops / args.batch / 1e9, 3),
+                   "whole_step_conv_tflops": round(step_flops / (dt / args.steps) / 1e12, 2)},
+    }
+    peak = PEAK_TFLOPS[args.dtype]
+    if use_events and n[0] > 0:
+        names = ["conv_igemm_kernel (forward)", "conv_igemm_kernel (data gradient)", "conv_wgrad_kernel"]
+        per = [{"kernel": names[k], "launches": int(n[k]), "avg_us": round(1e3 * ms[k] / max(n[k], 1), 2),
+                "tflops": round(fl[k] / max(ms[k], 1e-9) / 1e9, 2),
+                "share_of_step": round(ms[k] / (1e3 * dt), 4)} for k in range(3)]
+        t_ig, f_ig = ms[0] + ms[1], fl[0] + fl[1]  # same kernel template: forward + data gradient
+        ach = f_ig / t_ig / 1e9
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": None,
+                           "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+                           "launches": int(n[0] + n[1]),
+                           "avg_launch_us": round(1e3 * t_ig / (n[0] + n[1]), 2),
+                           "flop_per_launch": round(f_ig / (n[0] + n[1]), 1), "per_kernel": per}
+    else:
+        out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
+                           "traffic": None}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.cpu_steps)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "engine.h"
 
@@ -16,6 +17,29 @@ int set_error(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+}  // namespace d3f
+
+// ---- HIP-event profiling of the contraction kernels ------------------------------------------
+namespace d3f {
+struct ProfRec {
+  hipEvent_t a, b;
+  int cls;
+  double flops;
+};
+static std::vector<ProfRec> g_prof;  // pre-created event pairs
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+bool prof_enabled() { return g_prof_on && g_prof_used < g_prof.size(); }
+void prof_begin(int cls, double flops, hipStream_t s) {
+  ProfRec& r = g_prof[g_prof_used];
+  r.cls = cls;
+  r.flops = flops;
+  (void)hipEventRecord(r.a, s);
+}
+void prof_end(hipStream_t s) {
+  (void)hipEventRecord(g_prof[g_prof_used].b, s);
+  ++g_prof_used;
 }
 }  // namespace d3f
 
@@ -71,6 +95,40 @@ static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p) {
 extern "C" {
 
 int d3f_version(void) { return 100; }
+
+int d3f_profile_enable(int max_launches) {
+  if (max_launches <= 0) {
+    g_prof_on = false;
+    return 0;
+  }
+  while ((int)g_prof.size() < max_launches) {
+    ProfRec r;
+    D3F_HIP(hipEventCreate(&r.a));
+    D3F_HIP(hipEventCreate(&r.b));
+    r.cls = 0;
+    r.flops = 0;
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return 0;
+}
+int d3f_profile_collect(double ms[3], int64_t launches[3], double flops[3]) {
+  D3F_CHECK(ms && launches && flops, "profile_collect: null argument");
+  for (int k = 0; k < 3; ++k) { ms[k] = 0; launches[k] = 0; flops[k] = 0; }
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    ProfRec& r = g_prof[i];
+    D3F_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    D3F_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cls] += (double)t;
+    launches[r.cls] += 1;
+    flops[r.cls] += r.flops;
+  }
+  const int dropped = (g_prof_on && g_prof_used >= g_prof.size()) ? 1 : 0;
+  g_prof_used = 0;
+  return dropped ? set_error(1, "profile buffer filled up: some launches were not timed") : 0;
+}
 const char* d3f_last_error(void) { return g_err; }
 
 // ---- whole network ------------------------------------------------------------------------

@@ -53,6 +53,17 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
+// ---- raw buffer loads: out-of-range lanes read zeros in hardware (no branch, no select) --------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;  // every descriptor here covers < 2 GiB
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;    // elements per 16-byte vector
@@ -65,6 +76,15 @@ template <> struct Elem<bf16_t> {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------
+// Optional per-launch timing with HIP events on the launch stream (c_api.hip); used by bench.py
+// to report achieved FLOP/s of the contraction kernels against the MFMA roofline.
+// ---------------------------------------------------------------------------------------
+enum ProfClass : int { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_WGRAD = 2, PROF_NUM = 3 };
+bool prof_enabled();
+void prof_begin(int cls, double flops, hipStream_t s);
+void prof_end(hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (forward and data-gradient): conv_igemm.hip
@@ -86,6 +106,7 @@ struct ConvParams {
   const float* scale;  // per-out-channel scale (EVAL) / bias (HEAD)
   const float* shift;  // per-out-channel shift (EVAL)
   const void* res;     // residual NHWC (EVAL) or null
+  unsigned src0_bytes, src1_bytes, w_bytes;  // extents for the buffer descriptors (filled by plan)
   int B, Hv, Wv;       // virtual input extent (after upsample / zero insertion)
   int C0, C1;          // C0 + C1 = Cin (padded to a vector multiple)
   int H0s, W0s;        // physical extent of src0 = (Hv, Wv) >> shift0
@@ -100,6 +121,7 @@ struct ConvParams {
   int acc0, acc1;      // CONV_DGRAD: read-modify-write destinations
   int mode;
   int relu;
+  double flops;        // algorithmic FLOPs (2*MAC, unpadded channels) of this launch, for profiling
 };
 
 struct ConvTile {
@@ -117,6 +139,7 @@ struct WgradParams {
   const void* src0;  // conv input, same gather description as ConvParams
   const void* src1;
   float* partial;    // [splits][Cout][KH*KW][Cin] fp32 slabs
+  unsigned dy_bytes, src0_bytes, src1_bytes;  // extents for the buffer descriptors (filled by plan)
   int B, Hv, Wv, C0, C1, H0s, W0s, shift0;
   int Ho, Wo, Cout;
   int KH, KW, stride, pad;
@@ -124,6 +147,7 @@ struct WgradParams {
   int splits;   // pixel slabs
   int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;
+  double flops;  // algorithmic FLOPs of this launch, for profiling
 };
 int wgrad_plan(WgradParams& p, int dtype);  // fills splits/tiles; returns 0
 size_t wgrad_partial_floats(const WgradParams& p);

@@ -82,9 +82,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int chunk = tid & 7, rbase = tid >> 3;
 
-  const T* __restrict__ src0 = reinterpret_cast<const T*>(p.src0);
-  const T* __restrict__ src1 = reinterpret_cast<const T*>(p.src1);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
   const int Cin = p.C0 + p.C1;
 
   // ---- per-row output pixel -> input origin -----------------------------------------
@@ -122,10 +119,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
   int t_kh = 0, t_kw = 0, t_c = 0;
 
+  // Buffer descriptors (wave-uniform): lanes whose tap falls outside the image, whose row is past M
+  // or whose weight row is past CoutPad get the offset BUF_OOB and read zeros in hardware -- no
+  // divergent branch, no select after the load, so all loads of a k-tile are in flight together.
+  const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.src0, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+  const int w_row_bytes = p.Kpad * (int)sizeof(T);
+  unsigned woff[NVB];
+#pragma unroll
+  for (int j = 0; j < NVB; ++j) {
+    const int row = rbase + 32 * j;
+    const int n = n0 + row;
+    woff[j] = (row < BN && n < p.CoutPad) ? (unsigned)(n * w_row_bytes + chunk * 16) : BUF_OOB;
+  }
+
   uint4 ra[NVA], rb[NVB];
   auto load_tile = [&](int kt) {
     int kh, kw, c;
     bool tapvalid = true;
+    bool from0 = true;  // wave-uniform by construction (plan checks C0 % BKE == 0 when C1 > 0)
     if (SMALLC) {
       const int kk = kt * BKE + chunk * VE;
       const int tap = kk / Cin;
@@ -136,41 +149,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     } else {
       kh = t_kh;
       kw = t_kw;
-      c = t_c + chunk * VE;
+      from0 = t_c < p.C0;
+      c = (from0 ? t_c : t_c - p.C0) + chunk * VE;
       t_c += BKE;
       if (t_c >= Cin) {
         t_c = 0;
         if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
       }
     }
-    const bool from0 = c < p.C0;
-    const T* __restrict__ src = from0 ? src0 + c : src1 + (c - p.C0);
     const int Cs = from0 ? p.C0 : p.C1;
     const int sh = from0 ? p.shift0 : 0;
     const int Hs = from0 ? p.H0s : p.Hv;
     const int Ws = from0 ? p.W0s : p.Wv;
     const bool parity = from0 && p.zi;
+    unsigned off[NVA];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int iy = iy0[i] + kh, ix = ix0[i] + kw;
       bool v = tapvalid && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
       if (parity) v = v && (((iy | ix) & 1) == 0);
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (v) {
-        const long pix = ((long)bidx[i] * Hs + (iy >> sh)) * Ws + (ix >> sh);
-        val = *reinterpret_cast<const uint4*>(src + pix * Cs);
-      }
-      ra[i] = val;
+      const int pix = (bidx[i] * Hs + (iy >> sh)) * Ws + (ix >> sh);
+      off[i] = v ? (unsigned)(pix * Cs + c) * (unsigned)sizeof(T) : BUF_OOB;
+    }
+    if (from0) {
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) ra[i] = buf_load16(r0, off[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) ra[i] = buf_load16(r1, off[i]);
     }
 #pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int row = rbase + 32 * j;
-      const int n = n0 + row;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (row < BN && n < p.CoutPad)
-        val = *reinterpret_cast<const uint4*>(wgt + (long)n * p.Kpad + kt * BKE + chunk * VE);
-      rb[j] = val;
-    }
+    for (int j = 0; j < NVB; ++j)
+      rb[j] = buf_load16(rw, woff[j] == BUF_OOB ? BUF_OOB : woff[j] + (unsigned)(kt * BKE) * (unsigned)sizeof(T));
   };
 
   load_tile(0);
@@ -370,6 +380,12 @@ int conv_igemm_plan(ConvParams& p, int dtype) {
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "conv: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "conv: M");
   D3F_CHECK(p.CoutPad >= p.Cout, "conv: CoutPad");
+  D3F_CHECK(p.C1 == 0 || (p.C0 % bke) == 0, "conv: C0=%d must be a multiple of %d when a second source is concatenated", p.C0, bke);
+  const long es = dtype == D3F_F32 ? 4 : 2;
+  const long b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es, b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
+  const long bw = (long)p.CoutPad * p.Kpad * es;
+  D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
+  p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
   const ConvTile t = pick_tile(p);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
@@ -401,8 +417,11 @@ template <typename T> static int launch_t(const ConvParams& p, bool smallc, hipS
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   if (p.M == 0) return 0;
   const bool smallc = is_small_c(p, dtype);
-  if (dtype == D3F_F32) return launch_t<float>(p, smallc, stream);
-  return launch_t<bf16_t>(p, smallc, stream);
+  const bool prof = prof_enabled();
+  if (prof) prof_begin(p.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD, p.flops, stream);
+  const int rc = dtype == D3F_F32 ? launch_t<float>(p, smallc, stream) : launch_t<bf16_t>(p, smallc, stream);
+  if (prof) prof_end(stream);
+  return rc;
 }
 
 }  // namespace d3f

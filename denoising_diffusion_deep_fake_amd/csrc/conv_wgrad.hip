@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int split = blockIdx.y;
   const int Cin = p.C0 + p.C1;
 
-  const float* __restrict__ dy = reinterpret_cast<const float*>(p.dy);
-  const float* __restrict__ src0 = reinterpret_cast<const float*>(p.src0);
-  const float* __restrict__ src1 = reinterpret_cast<const float*>(p.src1);
+  // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip)
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(p.src0, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
 
   // loader roles
   const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*(256/VY)
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int xci = ci0 + xcv * 4;
   const bool yvalid_c = yco < p.Cout;
   const bool xvalid_c = xci < Cin;
-  const bool from0 = xci < p.C0;
-  const float* __restrict__ xsrc = from0 ? src0 + xci : src1 + (xci - p.C0);
+  const bool from0 = ci0 < p.C0;  // block-uniform: plan keeps ci tiles inside one source
+  const int xcl = from0 ? xci : xci - p.C0;
   const int Cs = from0 ? p.C0 : p.C1;
   const int sh = from0 ? p.shift0 : 0;
   const int Hs = from0 ? p.H0s : p.Hv;
@@ -83,33 +84,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int total_chunks = (p.M + KP - 1) / KP;
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-  float4 ry[NVY], rx[NVX];
+  uint4 ry[NVY], rx[NVX];
   auto load_chunk = [&](int ch) {
     const int pix0 = ch * KP;
 #pragma unroll
     for (int i = 0; i < NVY; ++i) {
       const int m = pix0 + yrow0 + i * YRS;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (yvalid_c && m < p.M) v = *reinterpret_cast<const float4*>(dy + (long)m * p.Cout + yco);
-      ry[i] = v;
+      const bool ok = yvalid_c && m < p.M;
+      ry[i] = buf_load16(rdy, ok ? (unsigned)(m * p.Cout + yco) * 4u : BUF_OOB);
     }
+    unsigned off[NVX];
 #pragma unroll
     for (int i = 0; i < NVX; ++i) {
       const int m = pix0 + xrow0 + i * XRS;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xvalid_c && m < p.M) {
-        const int b = m / HoWo;
-        const int r = m - b * HoWo;
-        const int oy = r / p.Wo;
-        const int ox = r - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + kh;
-        const int ix = ox * p.stride - p.pad + kw;
-        if ((unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv) {
-          const long pix = ((long)b * Hs + (iy >> sh)) * Ws + (ix >> sh);
-          v = *reinterpret_cast<const float4*>(xsrc + pix * Cs);
-        }
-      }
-      rx[i] = v;
+      const int b = m / HoWo;
+      const int r = m - b * HoWo;
+      const int oy = r / p.Wo;
+      const int ox = r - oy * p.Wo;
+      const int iy = oy * p.stride - p.pad + kh;
+      const int ix = ox * p.stride - p.pad + kw;
+      const bool ok = xvalid_c && m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+      const int pix = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
+      off[i] = ok ? (unsigned)(pix * Cs + xcl) * 4u : BUF_OOB;
+    }
+    if (from0) {
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) rx[i] = buf_load16(rx0, off[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) rx[i] = buf_load16(rx1, off[i]);
     }
   };
 
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   for (int ch = chunk_begin; ch < chunk_end; ++ch) {
 #pragma unroll
     for (int i = 0; i < NVY; ++i)
-      *reinterpret_cast<float4*>(&Ys[(yrow0 + i * YRS) * LY + ycv * 4]) = ry[i];
+      *reinterpret_cast<uint4*>(&Ys[(yrow0 + i * YRS) * LY + ycv * 4]) = ry[i];
 #pragma unroll
     for (int i = 0; i < NVX; ++i)
-      *reinterpret_cast<float4*>(&Xs[(xrow0 + i * XRS) * LX + xcv * 4]) = rx[i];
+      *reinterpret_cast<uint4*>(&Xs[(xrow0 + i * XRS) * LX + xcv * 4]) = rx[i];
     __syncthreads();
     if (ch + 1 < chunk_end) load_chunk(ch + 1);
 #pragma unroll
@@ -210,6 +213,11 @@ int wgrad_plan(WgradParams& p, int dtype) {
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
   const WTile t = pick_wtile(p);
+  D3F_CHECK(p.C1 == 0 || (p.C0 % t.bn) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t.bn);
+  const long bdy = (long)p.M * p.Cout * 4, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * 4,
+             b1 = (long)p.B * p.Hv * p.Wv * p.C1 * 4;
+  D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
+  p.dy_bytes = (unsigned)bdy; p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1;
   const int cin = p.C0 + p.C1;
   p.tiles_co = cdiv(p.Cout, t.bm);
   p.tiles_ci = cdiv(cin, t.bn);
@@ -234,12 +242,15 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits), block(256);
+  const bool prof = prof_enabled();
+  if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
   if (t.bm == 128)
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 128, 128, 2, 2, 1>), grid, block, 0, stream, p);
   else if (t.bm == 64)
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 2, 2, 1>), grid, block, 0, stream, p);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, 32, 1, 1, 4>), grid, block, 0, stream, p);
+  if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());
   return 0;
 }

@@ -155,6 +155,7 @@ int UnetEngine::plan_unit(Unit& u) {
   f.M = B * u.Ho * u.Wo;
   if (int rc = conv_igemm_plan(f, dtype)) return rc;
   const double macs = (double)f.M * u.Cout * u.KH * u.KW * u.CinReal;
+  f.flops = 2.0 * macs;
   fwd_flops += 2.0 * macs;
   bwd_flops += 2.0 * macs;  // weight gradient
   if (u.bn) {
@@ -173,6 +174,7 @@ int UnetEngine::plan_unit(Unit& u) {
   g.H0s = f.H0s; g.W0s = f.W0s; g.shift0 = u.up0;
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = f.M;
+  g.flops = 2.0 * macs;
   if (dtype == D3F_F32) {
     if (int rc = wgrad_plan(g, dtype)) return rc;
     const size_t wb = wgrad_partial_floats(g) * sizeof(float);
@@ -194,6 +196,7 @@ int UnetEngine::plan_unit(Unit& u) {
     d.mode = CONV_DGRAD;
     d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
     if (int rc = conv_igemm_plan(d, dtype)) return rc;
+    d.flops = 2.0 * macs;
     bwd_flops += 2.0 * macs;
     if (u.up0) {
       const size_t fb = (size_t)d.M * u.C0 * esize();

@@ -288,8 +288,10 @@ __global__ __launch_bounds__(256) void noise_blend_kernel(const float* __restric
   const int b = blockIdx.y;
   // x = 1/lam * log(1 / (y*(1-c) + c))   -- every step rounded to f32 like the torch expression
   const float t = __fadd_rn(__fmul_rn(y_uniform[b], one_minus_c), c);
-  const float r = __fmul_rn(inv_lam, logf(__fdiv_rn(1.0f, t)));
-  const float sa = sqrtf(__fsub_rn(1.0f, r)), sb = sqrtf(r);
+  // log / sqrt evaluated in double and rounded once: correctly rounded f32 results (the device's
+  // f32 logf / sqrtf are 1-2 ulp off the host libm the reference's CPU path uses); 3 ops per image
+  const float r = __fmul_rn(inv_lam, (float)log((double)__fdiv_rn(1.0f, t)));
+  const float sa = (float)sqrt((double)__fsub_rn(1.0f, r)), sb = (float)sqrt((double)r);
   if (r_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) r_out[b] = r;
   const long nvec = per_image / 4;
   const float4* __restrict__ xv = reinterpret_cast<const float4*>(x + (long)b * per_image);

@@ -1,0 +1,77 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU, full replica per rank.
+
+The only exchange step of the hot path is the gradient sum.  The backward pass of
+the C engine is cut into 4 buckets (head+decoder, layer4, layer3, rest) that become final in that
+order; as soon as bucket k's kernels are enqueued the flat gradient slice is handed to an
+asynchronous all-reduce (torch.distributed "nccl" == RCCL), which runs on the process group's own
+stream while the compute stream continues with bucket k+1.  `wait()` (called by FusedAdam.step)
+joins the streams; averaging is folded into the Adam kernel (grad_scale = 1/world_size).
+BatchNorm uses per-GPU batch statistics, as Lightning DDP would with the reference's Trainer flags
+(no sync_batchnorm); running statistics stay local (rank 0's are checkpointed).
+
+Nothing here exists in the reference (single device only, train_denoiser.py:43-48); it is the
+multi-GPU row of BASELINE.json.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend=None):
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return world, rank, local
+
+
+class BucketAllReducer:
+    """sum-all-reduce of gradient buckets, launched as they become ready, joined by wait()."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.works = []
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def __call__(self, segment, flat_slice):
+        if self.world_size > 1:
+            self.works.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class DataParallel:
+    """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
+
+    def __init__(self, model, optimizer, group=None):
+        self.model, self.optimizer = model, optimizer
+        self.reducer = BucketAllReducer(group)
+        self.world_size = self.reducer.world_size
+        if self.world_size > 1:
+            model.prepare()
+            dist.broadcast(model.flat_params, src=0, group=group)
+            dist.broadcast(model.flat_bn_stats, src=0, group=group)
+            model.mark_params_changed()
+            model.set_grad_sync(self.reducer)
+            optimizer.grad_scale = 1.0 / self.world_size
+            optimizer.before_step = self.reducer.wait
+
+
+def shard_indices(n, world_size, rank):
+    """contiguous, near-equal shard of range(n) for this rank (images are independent)."""
+    per = (n + world_size - 1) // world_size
+    return range(min(rank * per, n), min((rank + 1) * per, n))

@@ -1,0 +1,149 @@
+"""Fused optimiser-side updates over the Unet's flat parameter buffer.
+
+FusedAdam : torch.optim.Adam(params, lr, betas) as the reference configures it
+            (d3f/train_denoiser/lit_module.py:95; d3f/train_deep_fake/lit_module.py:116-120) in ONE
+            kernel launch over all 24.4 M parameters (csrc/optim.hip) instead of ~140 per-tensor updates.
+EMA       : ema_pytorch.EMA(model, beta, update_every, include_online_model=False) semantics
+            (d3f/train_deep_fake/lit_module.py:62-70,185; defaults update_after_step=100, inv_gamma=1,
+            power=2/3, min_value=0 -- SURVEY.md Appendix A.3) with the lerp as one launch per flat buffer.
+"""
+import copy
+
+import torch
+
+from . import ops
+from .unet import Unet
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, module=None, grad_scale=1.0):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if not isinstance(module, Unet):
+            raise TypeError("FusedAdam needs module=<the d3f Unet that owns these parameters>")
+        if [id(p) for p in params] != [id(p) for p in module.parameters()]:
+            raise ValueError("FusedAdam must be given exactly module.parameters()")
+        self.module = module
+        self.grad_scale = grad_scale
+        self.before_step = None  # e.g. DataParallel's reducer.wait
+        self._step = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if self.before_step is not None:
+            self.before_step()
+        m = self.module
+        flat, grads = m.flat_params, m.flat_grads
+        if flat is None or grads is None:
+            raise RuntimeError("FusedAdam.step() before any backward pass")
+        plist = m._param_list
+        first = plist[0].grad
+        if first is None:
+            return loss  # nothing to do (all grads cleared) -- same as torch.optim.Adam
+        if first.data_ptr() != grads.data_ptr():
+            # gradients were accumulated outside the flat buffer: gather them
+            off = 0
+            for p in plist:
+                grads[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                off += p.numel()
+        if self.exp_avg is None or self.exp_avg.data_ptr() == 0 or self.exp_avg.device != flat.device:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+        g = self.param_groups[0]
+        self._step += 1
+        ops.adam_step(flat, grads, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
+                      float(g["betas"][1]), float(g["eps"]), self._step, float(self.grad_scale))
+        m.mark_params_changed()
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["d3f_flat"] = {"step": self._step,
+                          "exp_avg": None if self.exp_avg is None else self.exp_avg.cpu(),
+                          "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.cpu()}
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        flat = sd.pop("d3f_flat", None)
+        super().load_state_dict(sd)
+        if flat is not None:
+            self._step = flat["step"]
+            dev = self.module.flat_params.device if self.module.flat_params is not None else "cuda"
+            self.exp_avg = None if flat["exp_avg"] is None else flat["exp_avg"].to(dev)
+            self.exp_avg_sq = None if flat["exp_avg_sq"] is None else flat["exp_avg_sq"].to(dev)
+
+
+class EMA(torch.nn.Module):
+    def __init__(self, model, beta=0.9999, update_every=1, update_after_step=100, inv_gamma=1.0,
+                 power=2 / 3, min_value=0.0, include_online_model=False):
+        super().__init__()
+        if include_online_model:
+            self.online_model = model
+        else:
+            self.__dict__["_online"] = [model]  # not a registered sub-module (kept out of state_dict)
+        self.include_online_model = include_online_model
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.register_buffer("initted", torch.tensor(False))
+        self.register_buffer("step", torch.tensor(0))
+        self._host_step = 0      # mirrors `step` without a device sync per update
+        self._host_initted = False
+
+    @property
+    def model(self):
+        return self.online_model if self.include_online_model else self.__dict__["_online"][0]
+
+    def get_current_decay(self, step=None):
+        step = self._host_step if step is None else step
+        epoch = max(step - self.update_after_step - 1, 0.0)
+        if epoch <= 0:
+            return 0.0
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        return min(max(value, self.min_value), self.beta)
+
+    def _flat_pairs(self):
+        on, em = self.model, self.ema_model
+        dev = next(on.parameters()).device
+        on.prepare(dev)
+        em.prepare(dev)
+        return [(em.flat_params, on.flat_params), (em.flat_bn_stats, on.flat_bn_stats)]
+
+    @torch.no_grad()
+    def copy_params_from_model_to_ema(self):
+        for e, o in self._flat_pairs():
+            e.copy_(o)
+        self.ema_model._rt["flat_nbt"].copy_(self.model._rt["flat_nbt"])
+        self.ema_model.mark_params_changed()
+
+    @torch.no_grad()
+    def update(self):
+        step = self._host_step
+        self._host_step += 1
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        if step <= self.update_after_step:
+            self.copy_params_from_model_to_ema()
+            return
+        if not self._host_initted:
+            self.copy_params_from_model_to_ema()
+            self._host_initted = True
+            self.initted.fill_(True)
+        w = 1.0 - self.get_current_decay()
+        for e, o in self._flat_pairs():
+            ops.ema_lerp(e, o, w)
+        self.ema_model.mark_params_changed()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._host_step = int(self.step.item())
+        self._host_initted = bool(self.initted.item())
+
+    def forward(self, *args, **kwargs):
+        return self.ema_model(*args, **kwargs)

@@ -391,6 +391,9 @@ class Unet(nn.Module):
         return self._run_forward(eng, xin, training=self.training)
 
     # flops of the conv contractions of one call (2*MAC), for roofline reporting
-    def conv_flops(self, B, H, W, device="cuda"):
-        eng = self._engine(B, H, W, torch.device(device, torch.cuda.current_device()))
+    def conv_flops(self, B, H, W, device=None):
+        device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        eng = self._engine(B, H, W, device)
         return eng.fwd_flops, eng.bwd_flops

@@ -35,6 +35,14 @@ extern "C" {
 int d3f_version(void);
 const char* d3f_last_error(void);
 
+/* Measurement hooks: when enabled, every launch of the three contraction kernels
+ * (class 0 = conv forward, 1 = conv data-gradient, 2 = conv weight-gradient) is bracketed by a pair
+ * of HIP events on the launch stream.  collect() waits for them and returns, per class, the summed
+ * kernel time (ms), the number of launches and their algorithmic FLOPs, then resets the buffer.
+ * max_launches <= 0 disables.  collect() returns 1 if the buffer overflowed. */
+int d3f_profile_enable(int max_launches);
+int d3f_profile_collect(double ms[3], int64_t launches[3], double flops[3]);
+
 /* ---------------------------------------------------------------------------------------
  * Whole-network handle: Unet(encoder_name, encoder_weights=None, in_channels, classes,
  * activation=None) for a fixed (B, H, W, dtype).
