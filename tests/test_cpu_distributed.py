@@ -1,0 +1,57 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient all-reduce that the data-parallel path uses
+(denoising_diffusion_deep_fake_amd/distributed.py).  The HIP network itself needs a GPU; what is
+covered here is the exchange step: buckets reduced as they become ready, joined by wait(), averaged
+by the optimiser's grad_scale, plus the contiguous sharding helper."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ranges, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer, init_process_group, shard_indices
+    w, r, _ = init_process_group("gloo")
+    assert (w, r) == (world, rank)
+    n = ranges[0][1]
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = BucketAllReducer()
+    assert red.world_size == world
+    for seg, (b, e) in enumerate(ranges):  # back to front, like the backward pass
+        red(seg, flat[b:e])
+    red.wait()
+    expect = torch.arange(n, dtype=torch.float32) * sum(k + 1 for k in range(world))
+    ok = torch.equal(flat, expect)
+    shard = list(shard_indices(10, world, rank))
+    ret[rank] = (ok, shard)
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_world2():
+    world = 2
+    ranges = [(700, 1000), (400, 700), (150, 400), (0, 150)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ranges, ret), nprocs=world, join=True)
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == [0, 1, 2, 3, 4] and ret[1][1] == [5, 6, 7, 8, 9]
+
+
+def test_single_process_is_a_noop():
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer, env_world, shard_indices
+    red = BucketAllReducer()
+    t = torch.ones(4)
+    red(0, t)
+    red.wait()
+    assert torch.equal(t, torch.ones(4)) and red.world_size == 1
+    assert list(shard_indices(5, 1, 0)) == [0, 1, 2, 3, 4]
+    assert list(shard_indices(3, 4, 3)) == []
