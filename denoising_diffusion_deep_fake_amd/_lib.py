@@ -52,9 +52,10 @@ PROTOTYPES = {
     "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
     "d3f_conv_packed_bytes": (_sz, [_i, _desc, _i]),
     "d3f_conv_pack_weights": (_i, [_i, _desc, _p, _p, _p, _p]),
-    "d3f_conv_stats_floats": (_sz, [_i, _desc, C.POINTER(_i)]),
-    "d3f_conv_forward": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p]),
-    "d3f_conv_backward_data": (_i, [_i, _desc, _p, _p, _p, _p, _i, _i, _p]),
+    "d3f_conv_workspace_bytes": (_sz, [_i, _desc, _i]),
+    "d3f_conv_stats_floats": (_sz, [_i, _desc, _i, C.POINTER(_i)]),
+    "d3f_conv_forward": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p, _p]),
+    "d3f_conv_backward_data": (_i, [_i, _desc, _p, _p, _p, _p, _i, _i, _p, _p]),
     "d3f_conv_backward_weight_workspace_bytes": (_sz, [_i, _desc]),
     "d3f_conv_backward_weight": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p]),
     "d3f_bn_finalize": (_i, [_p, _i, _i, _i64, _p, _p, _p, _p, _p, _p]),

@@ -79,7 +79,7 @@ static Geo geo(int dtype, const d3f_conv_desc* d) {
   return g;
 }
 
-static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p) {
+static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk = false) {
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
   std::memset(&p, 0, sizeof(p));
@@ -89,7 +89,25 @@ static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p) {
   p.Ho = g.Ho; p.Wo = g.Wo; p.Cout = d->Cout; p.CoutPad = g.CoutPad; p.Kpad = g.Kpad;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.M = d->B * g.Ho * g.Wo;
-  return conv_igemm_plan(p, dtype);
+  p.mode = CONV_RAW_STATS;
+  return conv_igemm_plan(p, dtype, allow_splitk);
+}
+
+static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk) {
+  if (int rc = desc_check(dtype, d)) return rc;
+  const Geo g = geo(dtype, d);
+  const int s2 = d->stride == 2;
+  D3F_CHECK(s2 ? (g.Ho * 2 == d->H && g.Wo * 2 == d->W) : (g.Ho == d->H && g.Wo == d->W),
+            "conv_backward_data: needs a 'same' (stride 1) or exactly halving (stride 2) conv");
+  std::memset(&p, 0, sizeof(p));
+  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = g.CoutD; p.C1 = 0;
+  p.H0s = g.Ho; p.W0s = g.Wo; p.shift0 = s2; p.zi = s2;
+  p.Ho = d->H; p.Wo = d->W; p.Cout = g.Cin; p.CoutPad = g.CinRows; p.Kpad = g.KpadD;
+  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
+  p.M = d->B * d->H * d->W;
+  p.mode = CONV_DGRAD;
+  p.out_c0 = d->C1 > 0 ? d->C0 : g.Cin;
+  return conv_igemm_plan(p, dtype, allow_splitk);
 }
 
 extern "C" {
@@ -219,40 +237,33 @@ int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, voi
   return pack_weights_launch(dtype, w, d->Cout, d->CinReal, g.Cin, d->KH, d->KW, w_fwd, g.CoutPad, g.Kpad,
                              w_dgrad, g.CinRows, g.KpadD, (hipStream_t)stream);
 }
-size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int* tiles) {
+size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
   ConvParams p;
-  if (fwd_params(dtype, d, p) != 0) return 0;
-  if (tiles) *tiles = p.tiles_m;
-  return (size_t)p.tiles_m * p.CoutPad * 2;
+  const int rc = which == 0 ? fwd_params(dtype, d, p, true) : dgrad_params(dtype, d, p, true);
+  return rc != 0 ? 0 : conv_splitk_floats(p) * sizeof(float);
+}
+size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int with_workspace, int* tiles) {
+  ConvParams p;
+  if (fwd_params(dtype, d, p, with_workspace != 0) != 0) return 0;
+  if (tiles) *tiles = p.stat_rows;
+  return (size_t)p.stat_rows * p.CoutPad * 2;
 }
 int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
-                     const void* w_fwd, void* y, float* stats, void* stream) {
+                     const void* w_fwd, void* y, float* stats, void* workspace, void* stream) {
   ConvParams p;
-  if (int rc = fwd_params(dtype, d, p)) return rc;
+  if (int rc = fwd_params(dtype, d, p, workspace != nullptr)) return rc;
   D3F_CHECK(src0 && w_fwd && y && (d->C1 == 0 || src1), "conv_forward: null argument");
   p.src0 = src0; p.src1 = src1; p.w = w_fwd; p.out0 = y; p.stats = stats; p.mode = CONV_RAW_STATS;
+  p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   return conv_igemm_launch(p, dtype, (hipStream_t)stream);
 }
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
-                           void* dx0, void* dx1, int acc0, int acc1, void* stream) {
-  if (int rc = desc_check(dtype, d)) return rc;
-  const Geo g = geo(dtype, d);
-  D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
-  const int s2 = d->stride == 2;
-  D3F_CHECK(s2 ? (g.Ho * 2 == d->H && g.Wo * 2 == d->W) : (g.Ho == d->H && g.Wo == d->W),
-            "conv_backward_data: needs a 'same' (stride 1) or exactly halving (stride 2) conv");
-  D3F_CHECK(d->Cout % (dtype == D3F_F32 ? 4 : 8) == 0 || true, "unreachable");
+                           void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream) {
   ConvParams p;
-  std::memset(&p, 0, sizeof(p));
-  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = g.CoutD; p.C1 = 0;
-  p.H0s = g.Ho; p.W0s = g.Wo; p.shift0 = s2; p.zi = s2;
-  p.Ho = d->H; p.Wo = d->W; p.Cout = g.Cin; p.CoutPad = g.CinRows; p.Kpad = g.KpadD;
-  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
-  p.M = d->B * d->H * d->W;
-  p.mode = CONV_DGRAD;
-  p.out_c0 = d->C1 > 0 ? d->C0 : g.Cin;
-  if (int rc = conv_igemm_plan(p, dtype)) return rc;
+  if (int rc = dgrad_params(dtype, d, p, workspace != nullptr)) return rc;
+  D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
   p.src0 = dy; p.w = w_dgrad; p.out0 = dx0; p.out1 = dx1; p.acc0 = acc0; p.acc1 = acc1;
+  p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   return conv_igemm_launch(p, dtype, (hipStream_t)stream);
 }
 static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {

@@ -117,6 +117,9 @@ struct ConvParams {
   int KH, KW, stride, pad;
   int M;               // B*Ho*Wo
   int tiles_m, tiles_n;
+  float* partial;      // split-K slabs [splitk][M][Cout] f32 (null: no split)
+  int splitk;          // k-tile ranges (grid.y); > 1 only when `partial` is given
+  int stat_rows;       // rows of the stats partial array: tiles_m, or the reduce kernel's row blocks
   int out_c0;          // CONV_DGRAD: channels [0,out_c0) -> out0, the rest -> out1
   int acc0, acc1;      // CONV_DGRAD: read-modify-write destinations
   int mode;
@@ -128,7 +131,10 @@ struct ConvTile {
   int BM, BN;
 };
 // chooses the tile configuration for a problem; tiles_m/tiles_n are filled in p.
-int conv_igemm_plan(ConvParams& p, int dtype);
+// allow_splitk: the caller can provide `partial` (conv_splitk_floats(p) floats) -- deep layers
+// whose M x Cout yields too few workgroups then split the K loop over grid.y.
+int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk = false);
+size_t conv_splitk_floats(const ConvParams& p);
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------

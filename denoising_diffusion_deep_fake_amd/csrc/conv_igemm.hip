@@ -18,6 +18,8 @@
 // (register-staged prefetch, one LDS buffer, two barriers per k-tile).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace d3f {
 
 template <typename T, int MT> struct Mma;
@@ -115,9 +117,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < M_::NREG; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.Kpad / BKE;
+  const int nk_total = p.Kpad / BKE;
+  // split-K: grid.y cuts the k-tile range; each slice writes raw accumulators to its slab
+  const int kt_begin = (int)((long)nk_total * blockIdx.y / p.splitk);
+  const int kt_end = (int)((long)nk_total * (blockIdx.y + 1) / p.splitk);
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
   int t_kh = 0, t_kw = 0, t_c = 0;
+  if (!SMALLC && kt_begin > 0) {
+    const int cpos = kt_begin * BKE;
+    const int tap = cpos / Cin;
+    t_c = cpos - tap * Cin;
+    t_kh = tap / p.KW;
+    t_kw = tap - t_kh * p.KW;
+  }
 
   // Buffer descriptors (wave-uniform): lanes whose tap falls outside the image, whose row is past M
   // or whose weight row is past CoutPad get the offset BUF_OOB and read zeros in hardware -- no
@@ -183,11 +195,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       rb[j] = buf_load16(rw, woff[j] == BUF_OOB ? BUF_OOB : woff[j] + (unsigned)(kt * BKE) * (unsigned)sizeof(T));
   };
 
-  load_tile(0);
+  load_tile(kt_begin);
   const int fr = (MT == 32) ? (lane & 31) : (lane & 15);
   const int fq = (MT == 32) ? (lane >> 5) : (lane >> 4);
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     // stage the prefetched tile
 #pragma unroll
     for (int i = 0; i < NVA; ++i)
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       if (row < BN) *reinterpret_cast<uint4*>(&Bs[row * LDS_ROW + chunk * 4]) = rb[j];
     }
     __syncthreads();
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < kt_end) load_tile(kt + 1);
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -225,7 +237,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int n_l = fr;
   auto m_local = [&](int r) { return (MT == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * fq) : (4 * fq + r); };
 
-  if (p.mode == CONV_RAW_STATS) {
+  if (p.splitk > 1) {
+    float* __restrict__ slab = p.partial + (long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * TN + j * MT + n_l;
+#pragma unroll
+        for (int r = 0; r < M_::NREG; ++r) {
+          const int m = m0 + wm * TM + i * MT + m_local(r);
+          if (m < p.M && n < p.Cout) slab[(long)m * p.Cout + n] = acc[i][j][r];
+        }
+      }
+  } else if (p.mode == CONV_RAW_STATS) {
     T* __restrict__ out = reinterpret_cast<T*>(p.out0);
     float s1[FN], s2[FN];
 #pragma unroll
@@ -343,6 +368,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// split-K epilogue: sums the slabs in a fixed order and applies the mode's store
+//   CONV_RAW_STATS : out0[m][n] = sum (+ per-channel sum / sumsq partial per row block)
+//   CONV_DGRAD     : dual-destination store with optional accumulate
+// ---------------------------------------------------------------------------------------
+constexpr int SK_ROWS = 16;  // rows per reduce workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+  __shared__ float red[256 * 4 * 2];
+  const int VC = p.Cout / 4;   // 16-byte vectors per row; 256 % VC == 0 (plan)
+  const int RP = 256 / VC;     // rows per pass
+  const int cv = threadIdx.x % VC, r0 = threadIdx.x / VC;
+  const int m_begin = blockIdx.x * SK_ROWS;
+  const int m_end = min(m_begin + SK_ROWS, p.M);
+  const long MN = (long)p.M * p.Cout;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
+  T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
+  for (int m = m_begin + r0; m < m_end; m += RP) {
+    const long e = (long)m * p.Cout + cv * 4;
+    float4 v = *reinterpret_cast<const float4*>(p.partial + e);
+    for (int z = 1; z < p.splitk; ++z) {
+      const float4 w = *reinterpret_cast<const float4*>(p.partial + z * MN + e);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float vv[4] = {v.x, v.y, v.z, v.w};
+    if (p.mode == CONV_RAW_STATS) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1[k] += vv[k];
+        s2[k] += vv[k] * vv[k];
+        o0[e + k] = from_f32<T>(vv[k]);
+      }
+    } else {  // CONV_DGRAD
+      const int n = cv * 4;
+      const bool first = n < p.out_c0;
+      T* __restrict__ dst = first ? o0 + (long)m * p.out_c0 + n : o1 + (long)m * (p.Cout - p.out_c0) + (n - p.out_c0);
+      const bool accum = first ? p.acc0 : p.acc1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = vv[k];
+        if (accum) x += to_f32<T>(dst[k]);
+        dst[k] = from_f32<T>(x);
+      }
+    }
+  }
+  if (p.mode == CONV_RAW_STATS && p.stats != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[(threadIdx.x * 4 + k) * 2 + 0] = s1[k];
+      red[(threadIdx.x * 4 + k) * 2 + 1] = s2[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * p.Cout; t += 256) {
+      const int c = t >> 1, which = t & 1;
+      const int v = c >> 2, k = c & 3;
+      float s = 0.f;
+      for (int rr = 0; rr < RP; ++rr) s += red[(((rr * VC + v) * 4) + k) * 2 + which];
+      p.stats[((long)blockIdx.x * p.CoutPad + c) * 2 + which] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: tile selection + launch
 // ---------------------------------------------------------------------------------------
 static bool is_small_c(const ConvParams& p, int dtype) {
@@ -362,7 +451,11 @@ static ConvTile pick_tile(const ConvParams& p) {
   return {64, 64};
 }
 
-int conv_igemm_plan(ConvParams& p, int dtype) {
+size_t conv_splitk_floats(const ConvParams& p) {
+  return p.splitk > 1 ? (size_t)p.splitk * p.M * p.Cout : 0;
+}
+
+int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   const int bke = dtype == D3F_F32 ? 32 : 64;
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "conv: bad dtype %d", dtype);
@@ -389,12 +482,30 @@ int conv_igemm_plan(ConvParams& p, int dtype) {
   const ConvTile t = pick_tile(p);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
+  p.splitk = 1;
+  p.stat_rows = p.tiles_m;
+  // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop
+  const long base = (long)p.tiles_m * p.tiles_n;
+  const int nk = p.Kpad / bke;
+  const int vc = p.Cout / 4;
+  static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob
+  if (allow_splitk && !no_splitk && !is_small_c(p, dtype) && base < 384 && (p.Cout % 4) == 0 && vc <= 256 &&
+      (256 % vc) == 0 && (p.mode == CONV_RAW_STATS || p.mode == CONV_DGRAD) &&
+      (p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0)) {
+    int sk = (int)((640 + base - 1) / base);
+    while (sk > 1 && nk / sk < 6) --sk;  // keep >= 6 k-tiles per slice
+    if (sk > 8) sk = 8;
+    if (sk > 1) {
+      p.splitk = sk;
+      p.stat_rows = cdiv(p.M, SK_ROWS);
+    }
+  }
   return 0;
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MT>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk), block(256);
   if (smallc)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true>), grid, block, 0, stream, p);
   else
@@ -417,9 +528,20 @@ template <typename T> static int launch_t(const ConvParams& p, bool smallc, hipS
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   if (p.M == 0) return 0;
   const bool smallc = is_small_c(p, dtype);
+  ConvParams q = p;
+  if (q.partial == nullptr) q.splitk = 1;
+  D3F_CHECK(q.splitk == 1 || q.stat_rows == cdiv(q.M, SK_ROWS), "conv: split-K params were not planned");
   const bool prof = prof_enabled();
-  if (prof) prof_begin(p.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD, p.flops, stream);
-  const int rc = dtype == D3F_F32 ? launch_t<float>(p, smallc, stream) : launch_t<bf16_t>(p, smallc, stream);
+  if (prof) prof_begin(q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD, q.flops, stream);
+  int rc = dtype == D3F_F32 ? launch_t<float>(q, smallc, stream) : launch_t<bf16_t>(q, smallc, stream);
+  if (rc == 0 && q.splitk > 1) {
+    const dim3 grid((unsigned)cdiv(q.M, SK_ROWS)), block(256);
+    if (dtype == D3F_F32)
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, grid, block, 0, stream, q);
+    else
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel<bf16_t>, grid, block, 0, stream, q);
+    if (hipGetLastError() != hipSuccess) rc = set_error(-2, "conv split-K reduce launch failed");
+  }
   if (prof) prof_end(stream);
   return rc;
 }

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
+// Each thread owns one weight element and sums its `splits` slab values with 8 loads in flight
+// (a serial loop is latency-bound: 114 dependent-issue round trips for the layer1 shapes).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            int splits, int CoutP, int Cout, int Cin,
                                                            int CinReal, int taps,
@@ -189,8 +191,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int tap = (int)(t % taps);
     const int co = (int)(t / taps);
     if (ci >= CinReal || co >= Cout) continue;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(long)k * n + e];
+    const float* __restrict__ src = partial + e;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src[(long)(k + u) * n];
+    }
+    for (; k < splits; ++k) acc[0] += src[(long)k * n];
+    // fixed summation tree -> bitwise reproducible
+    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     float* dst = dw + ((long)co * CinReal + ci) * taps + tap;
     *dst = accumulate ? (*dst + s) : s;
   }

@@ -153,13 +153,15 @@ int UnetEngine::plan_unit(Unit& u) {
   f.Ho = u.Ho; f.Wo = u.Wo; f.Cout = u.Cout; f.CoutPad = u.CoutPad; f.Kpad = u.Kpad;
   f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;
   f.M = B * u.Ho * u.Wo;
-  if (int rc = conv_igemm_plan(f, dtype)) return rc;
+  f.mode = u.bn ? CONV_RAW_STATS : CONV_HEAD_NCHW;
+  if (int rc = conv_igemm_plan(f, dtype, true)) return rc;
+  if (conv_splitk_floats(f) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(f) * sizeof(float);
   const double macs = (double)f.M * u.Cout * u.KH * u.KW * u.CinReal;
   f.flops = 2.0 * macs;
   fwd_flops += 2.0 * macs;
   bwd_flops += 2.0 * macs;  // weight gradient
   if (u.bn) {
-    const size_t sb = (size_t)f.tiles_m * u.CoutPad * 2 * sizeof(float);
+    const size_t sb = (size_t)f.stat_rows * u.CoutPad * 2 * sizeof(float);
     if (sb > stats_bytes) stats_bytes = sb;
     const size_t pb = (size_t)bn_bwd_reduce_blocks((long)f.M, u.Cout, dtype) * u.Cout * 2 * sizeof(float);
     if (pb > bnpart_bytes) bnpart_bytes = pb;
@@ -195,7 +197,8 @@ int UnetEngine::plan_unit(Unit& u) {
     d.M = B * u.Hv * u.Wv;
     d.mode = CONV_DGRAD;
     d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
-    if (int rc = conv_igemm_plan(d, dtype)) return rc;
+    if (int rc = conv_igemm_plan(d, dtype, true)) return rc;
+    if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
     d.flops = 2.0 * macs;
     bwd_flops += 2.0 * macs;
     if (u.up0) {
@@ -352,6 +355,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   dfull_off = alloc(dfull_bytes);
   wpart_off = alloc(wpart_bytes);
   bsum_off = alloc((size_t)classes * CS_PARTS * sizeof(float));
+  splitk_off = alloc(splitk_bytes);
   workspace_bytes = ws_top;
 
   // ---- gradient buckets (contiguous slices of the flat gradient, ready in this order) ----
@@ -437,8 +441,9 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
       p.mode = CONV_RAW_STATS;
       p.out0 = T(u.y);
       p.stats = reinterpret_cast<float*>(ws + stats_off);
+      p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
-      if (int rc = bn_finalize_launch(p.stats, p.tiles_m, u.Cout, u.CoutPad, (long)p.M,
+      if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, (long)p.M,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
                                       coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s))
@@ -539,6 +544,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       }
       d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
       d.acc1 = op.acc1 ? 1 : 0;
+      d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(d, dtype, s)) return rc;
     }
   }

@@ -51,26 +51,38 @@ static inline int grid_for(long work_items, int per_block = 256, int cap = 2048)
 // ------------------------------------------------------------------------------------------
 // BatchNorm forward
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ stats, int tiles, int C, int Cpad, double count,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
-    float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int t = lane; t < tiles; t += 64) {
-    const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * Cpad + c) * 2);
-    s1 += (double)v.x;
-    s2 += (double)v.y;
-  }
+// one workgroup per channel: 256 lanes stride over the m-tile partials (up to 8192 of them for the
+// 256x16 tiles), f64 accumulation, wave shuffle + LDS tree
+__device__ __forceinline__ void block_sum2(double& s1, double& s2) {
+  __shared__ double red[2][4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     s1 += __shfl_xor(s1, o);
     s2 += __shfl_xor(s2, o);
   }
-  if (lane == 0) {
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ stats, int tiles, int C, int Cpad, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
+    float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * Cpad + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -78,8 +90,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float g = gamma[c], b = beta[c];
     mean_o[c] = (float)mean;
     invstd_o[c] = (float)invstd;
-    const float sc = (float)((double)g * invstd);
-    scale_o[c] = sc;
+    scale_o[c] = (float)((double)g * invstd);
     shift_o[c] = (float)((double)b - mean * (double)g * invstd);
     if (running_mean != nullptr) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -93,7 +104,7 @@ int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long coun
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* mean, float* invstd,
                        float* scale, float* shift, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, stats, tiles, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, stats, tiles, C,
                      Cpad, (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean,
                      invstd, scale, shift);
   D3F_HIP(hipGetLastError());
@@ -271,21 +282,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = lane; t < nblocks; t += 64) {
+  for (int t = threadIdx.x; t < nblocks; t += 256) {
     const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * C + c) * 2);
     s1 += (double)v.x;
     s2 += (double)v.y;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o);
-    s2 += __shfl_xor(s2, o);
-  }
-  if (lane == 0) {
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
     const float db = (float)s1, dg = (float)s2;
     if (dgamma != nullptr) {
       dgamma[c] = accumulate ? dgamma[c] + dg : dg;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
                            int accumulate, float* coef, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partial, nblocks,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblocks,
                      C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
   D3F_HIP(hipGetLastError());
   return 0;

@@ -57,25 +57,36 @@ def pack_weights(d, w, dtype=F32, dgrad=True):
     return wf, wd
 
 
-def conv_forward(d, src0, src1, wf, dtype=F32, want_stats=True):
+def _conv_ws(d, dtype, which, dev, splitk):
+    if not splitk:
+        return None
+    n = _lib.lib().d3f_conv_workspace_bytes(dtype, C.byref(d), which)
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
+
+
+def conv_forward(d, src0, src1, wf, dtype=F32, want_stats=True, splitk=False):
+    """splitk=True hands the kernel a workspace so small-M layers may split their K loop."""
     L = _lib.lib()
     ho, wo = out_hw(d)
     y = torch.empty((d.B, ho, wo, d.Cout), dtype=_tdtype(dtype), device=_dev(src0))
+    ws = _conv_ws(d, dtype, 0, y.device, splitk)
     tiles = C.c_int()
-    n = L.d3f_conv_stats_floats(dtype, C.byref(d), C.byref(tiles))
+    n = L.d3f_conv_stats_floats(dtype, C.byref(d), int(splitk), C.byref(tiles))
     stats = torch.zeros(n, dtype=torch.float32, device=y.device) if want_stats else None
-    check(L.d3f_conv_forward(dtype, C.byref(d), ptr(src0), ptr(src1), ptr(wf), ptr(y), ptr(stats), stream_ptr()))
+    check(L.d3f_conv_forward(dtype, C.byref(d), ptr(src0), ptr(src1), ptr(wf), ptr(y), ptr(stats), ptr(ws),
+                             stream_ptr()))
     return y, stats, tiles.value
 
 
-def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False):
+def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False, splitk=False):
     dev = _dev(dy)
+    ws = _conv_ws(d, dtype, 1, dev, splitk)
     if dx0 is None:
         dx0 = torch.empty((d.B, d.H, d.W, d.C0), dtype=_tdtype(dtype), device=dev)
     if dx1 is None and d.C1 > 0:
         dx1 = torch.empty((d.B, d.H, d.W, d.C1), dtype=_tdtype(dtype), device=dev)
     check(_lib.lib().d3f_conv_backward_data(dtype, C.byref(d), ptr(dy), ptr(wd), ptr(dx0), ptr(dx1),
-                                            int(acc0), int(acc1), stream_ptr()))
+                                            int(acc0), int(acc1), ptr(ws), stream_ptr()))
     return dx0, dx1
 
 

@@ -110,13 +110,18 @@ int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, voi
 /* y = conv(cat(up(src0), src1)) NHWC; stats != NULL: per-channel (sum, sumsq) partials for
  * d3f_bn_finalize, d3f_conv_stats_floats() floats.  Replaces F.interpolate + torch.cat + conv2d
  * of smp's DecoderBlock / torchvision BasicBlock under lit_module.py:117. */
-size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int* tiles);
+/* `workspace` (optional, d3f_conv_workspace_bytes(.., which) bytes; which 0 = forward, 1 = data
+ * gradient) lets layers whose M x Cout yields too few workgroups split their K loop (split-K slabs
+ * + fixed-order reduce); the statistics partial layout then follows the reduce kernel, so pass the
+ * same with_workspace flag to d3f_conv_stats_floats. */
+size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which);
+size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int with_workspace, int* tiles);
 int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
-                     const void* w_fwd, void* y, float* stats, void* stream);
+                     const void* w_fwd, void* y, float* stats, void* workspace, void* stream);
 /* dx over the conv input: channels [0,C0) -> dx0 (full resolution even when upsample0),
  * [C0,C0+C1) -> dx1; acc*: add to the destination instead of overwriting */
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
-                           void* dx0, void* dx1, int acc0, int acc1, void* stream);
+                           void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream);
 /* dw in torch layout [Cout][CinReal][KH][KW] f32 */
 size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d);
 int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, const void* src0,

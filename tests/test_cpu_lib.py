@@ -89,4 +89,5 @@ def test_conv_descriptor_validation_on_host():
     d = _lib.ConvDesc(2, 16, 16, 64, 0, 0, 128, 3, 3, 2, 1, 64)
     assert lib.d3f_conv_packed_bytes(_lib.F32, C.byref(d), 0) == 128 * 576 * 4
     tiles = C.c_int()
-    assert lib.d3f_conv_stats_floats(_lib.F32, C.byref(d), C.byref(tiles)) == tiles.value * 128 * 2
+    assert lib.d3f_conv_stats_floats(_lib.F32, C.byref(d), 0, C.byref(tiles)) == tiles.value * 128 * 2
+    assert lib.d3f_conv_workspace_bytes(_lib.F32, C.byref(d), 0) > 0  # 128 rows x 128 channels: split-K

@@ -22,7 +22,7 @@ def ops():
     return o
 
 
-def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=None, seed=0):
+def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=None, seed=0, splitk=False):
     g = torch.Generator().manual_seed(seed)
     cin = C0 + C1
     cr = cin_real or cin
@@ -44,7 +44,7 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
     s0 = to_nhwc(x0, C0).cuda()
     s1 = to_nhwc(x1).cuda() if x1 is not None else None
     wf, wd = ops.pack_weights(d, w.cuda())
-    y, stats, tiles = ops.conv_forward(d, s0, s1, wf)
+    y, stats, tiles = ops.conv_forward(d, s0, s1, wf, splitk=splitk)
     torch.cuda.synchronize()
     y_h = to_nchw(y.cpu())
     assert rel_l2(y_h, y_ref) < TOL_CONV, ("fwd", rel_l2(y_h, y_ref))
@@ -62,7 +62,7 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
     assert rel_l2(dw.cpu(), wr.grad) < TOL_CONV, ("wgrad", rel_l2(dw.cpu(), wr.grad))
     # data gradient (the padded first conv never needs one)
     if cin_real is None:
-        dx0, dx1 = ops.conv_backward_data(d, dy_h, wd)
+        dx0, dx1 = ops.conv_backward_data(d, dy_h, wd, splitk=splitk)
         dxr = xin.grad
         assert rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]) < TOL_CONV, ("dgrad0", rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]))
         if C1:
@@ -75,7 +75,7 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
             assert rel_l2(to_nchw(low.cpu()), x0r.grad) < 1e-6
         # accumulate flag
         base = torch.randn(dx0.shape, generator=g).cuda()
-        acc, _ = ops.conv_backward_data(d, dy_h, wd, dx0=base.clone(), dx1=dx1, acc0=True)
+        acc, _ = ops.conv_backward_data(d, dy_h, wd, dx0=base.clone(), dx1=dx1, acc0=True, splitk=splitk)
         assert rel_l2(acc.cpu(), (base + dx0).cpu()) < 1e-6
 
 
@@ -96,6 +96,12 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
 def test_conv_fwd_dgrad_wgrad(ops, case):
     _conv_case(ops, *case)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_splitk_paths(ops, case):
+    # same shapes with a workspace: the planner splits the K loop wherever M x Cout is small
+    _conv_case(ops, *case, splitk=True)
 
 
 def test_conv_first_layer_7x7(ops):

@@ -18,11 +18,21 @@ pytestmark = pytest.mark.gpu
 # float64, hip / cpu-fp32: forward 1.5e-5 / 1.3e-5 at B=2 64x64, 1.3e-4 / 1.0e-4 at B=1 32x96; flat
 # gradient 1.0e-3 / 1.5e-3 at B=4 64x64).  The absolute caps only catch gross failures; a wrong
 # kernel shows up orders of magnitude above both.
-CAP_FWD, CAP_GRAD_FLAT, CAP_GRAD_TENSOR, NOISE = 1e-3, 1e-2, 5e-2, 4.0
+#
+# Gradients: the network is piecewise linear (ReLU, max-pool), so its gradient is discontinuous in
+# the activations and any two fp32 evaluations differ by mask flips: measured flat-gradient rel-L2
+# vs float64 on MI355X -- B=8 128x128: hip 3.0e-3 (split-K) / 6.6e-3 (no split-K), cpu-fp32 6.7e-3;
+# B=4 64x64: hip 3.5e-3 / 5.3e-4, cpu-fp32 3.4e-3.  Per tensor the error is bimodal: ~1e-6 when no mask
+# flips relative to the float64 run, ~1e-3..1e-2 when one does (seen for hip AND cpu-fp32, on different
+# tensors, e.g. decoder.blocks.4.conv2.0.weight 7.1e-4 vs 1.7e-6), so a per-tensor RATIO is meaningless.
+# Gates: flat gradient within NOISE_GRAD (=10) x the CPU-fp32 oracle's own distance and 3e-2 absolute;
+# every single tensor within 5e-2 absolute -- a wrong tap / mask / routing / missing accumulate is O(1).
+# Kernel-level exactness (1e-5) is established without this noise in tests/test_gpu_ops.py.
+CAP_FWD, CAP_GRAD_FLAT, CAP_GRAD_TENSOR, NOISE, NOISE_GRAD = 1e-3, 3e-2, 5e-2, 4.0, 10.0
 
 
-def _within(e_hip, e_cpu, cap, floor):
-    return e_hip < cap and e_hip < max(NOISE * e_cpu, floor)
+def _within(e_hip, e_cpu, cap, floor, noise=NOISE):
+    return e_hip < cap and e_hip < max(noise * e_cpu, floor)
 
 
 def _pair(seed=0, encoder="resnet34"):
@@ -68,6 +78,9 @@ def test_forward_train_and_eval(shape):
             assert rel_l2(sd[k], sd64[k]) < max(NOISE * rel_l2(sd_ref[k], sd64[k]), 1e-5), k
         if "num_batches_tracked" in k:
             assert sd[k].item() == sd_ref[k].item() == 1
+    # eval compares the eval kernels only: start all three from the same running statistics
+    net.load_state_dict(ref.state_dict())
+    ref64.load_state_dict(ref.state_dict())
     ref.eval()
     ref64.eval()
     net.eval()
@@ -111,14 +124,14 @@ def test_backward_and_adam_step():
                                             ref64.named_parameters()):
         assert n1 == n2 == n3 and p2.grad is not None, n1
         e_hip, e_cpu = rel_l2(p2.grad, p3.grad), rel_l2(p1.grad, p3.grad)
-        if not _within(e_hip, e_cpu, CAP_GRAD_TENSOR, 2e-4):
+        if not e_hip < CAP_GRAD_TENSOR:
             report.append((n1, e_hip, e_cpu))
     assert not report, report[:8]
     flat64 = torch.cat([p.grad.reshape(-1) for p in ref64.parameters()])
     flat_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     e_hip, e_cpu = rel_l2(net.flat_grads, flat64), rel_l2(flat_ref, flat64)
     print("flat gradient rel-L2 vs float64: hip %.3e cpu-fp32 %.3e" % (e_hip, e_cpu))
-    assert _within(e_hip, e_cpu, CAP_GRAD_FLAT, 2e-5), (e_hip, e_cpu)
+    assert _within(e_hip, e_cpu, CAP_GRAD_FLAT, 2e-5, NOISE_GRAD), (e_hip, e_cpu)
     # grads are views of the flat buffer (no copies)
     assert all(p.grad.data_ptr() >= net.flat_grads.data_ptr() for p in net.parameters())
     before = net.flat_params.clone()
