@@ -153,6 +153,7 @@ struct WgradParams {
   int splits;   // pixel slabs
   int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;
+  int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
   double flops;  // algorithmic FLOPs of this launch, for profiling
 };
 int wgrad_plan(WgradParams& p, int dtype);  // fills splits/tiles; returns 0

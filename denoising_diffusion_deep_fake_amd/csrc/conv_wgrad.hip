@@ -16,6 +16,8 @@
 // loss.backward() for the reference's U-Net.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace d3f {
 
 constexpr int KP = 32;  // pixels per k-chunk
@@ -218,6 +220,10 @@ static WTile pick_wtile(const WgradParams& p) {
   return {32, 32};
 }
 
+int wgrad_patch_variant(const WgradParams& p);
+void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy);
+int wgrad_patch_launch(const WgradParams& p, int variant, hipStream_t stream);
+
 int wgrad_plan(WgradParams& p, int dtype) {
   D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
   D3F_CHECK((p.C0 % 4) == 0 && (p.C1 % 4) == 0 && (p.Cout % 4) == 0,
@@ -230,6 +236,15 @@ int wgrad_plan(WgradParams& p, int dtype) {
              b1 = (long)p.B * p.Hv * p.Wv * p.C1 * 4;
   D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
   p.dy_bytes = (unsigned)bdy; p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1;
+  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p);
+  if (p.patch) {  // persistent patch kernel: one slab per workgroup column
+    int gx, gy;
+    wgrad_patch_grid(p, p.patch, &gx, &gy);
+    p.splits = gx;
+    p.chunks_per_split = 0;
+    p.tiles_co = p.tiles_ci = 0;
+    return 0;
+  }
   const int cin = p.C0 + p.C1;
   p.tiles_co = cdiv(p.Cout, t.bm);
   p.tiles_ci = cdiv(cin, t.bn);
@@ -251,6 +266,13 @@ size_t wgrad_partial_floats(const WgradParams& p) {
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
   if (p.M == 0) return 0;
+  if (p.patch) {
+    const bool prof = prof_enabled();
+    if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
+    const int rc = wgrad_patch_launch(p, p.patch, stream);
+    if (prof) prof_end(stream);
+    return rc;
+  }
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits), block(256);

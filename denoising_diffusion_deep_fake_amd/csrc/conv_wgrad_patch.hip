@@ -1,0 +1,238 @@
+// Weight gradient for the high-resolution, few-channel layers (decoder blocks 3/4, the head, the
+// 7x7 stem): "patch" formulation.
+//
+// The tap-parallel kernel (conv_wgrad.hip) re-reads dY and X once per filter tap -- 9x (49x for the
+// stem) the algorithmic bytes, which is what bounds it on these layers (1 M pixels, <= 32 channels).
+// Here a workgroup stages ONE spatial tile of dY (TH x TW output pixels) and the matching halo patch
+// of X ((TH-1)*S+KS) x ((TW-1)*S+KS) input pixels, gathered through the same up-sample / two-source
+// description as the forward pass) in LDS, then runs every tap from LDS: the B operand of
+//     dW[co][(tap, ci)] += sum_pixels dY[pixel][co] * X[pixel*S + tap][ci]
+// is the patch read at a compile-time tap offset, so the inner loop is ds_read_b32 (immediate offsets)
+// + MFMA only.  Each wave owns the accumulators of ALL (tap, ci) column tiles for the rows it sweeps,
+// keeps them in registers across the tiles of a persistent loop, and the four waves are summed through
+// LDS once at the end.  Output: one fp32 slab per workgroup in the [split][Cout][tap][Cin] layout of
+// conv_wgrad.hip, reduced by the same fixed-order wgrad_reduce_kernel (bitwise reproducible).
+#include "common.h"
+
+namespace d3f {
+
+constexpr int PT_TH = 8;  // tile rows: 2 per wave
+
+template <int MT> struct PAcc;
+template <> struct PAcc<32> { using T = f32x16; static constexpr int N = 16; };
+template <> struct PAcc<16> { using T = f32x4; static constexpr int N = 4; };
+
+template <int MT> __device__ __forceinline__ void pmma(typename PAcc<MT>::T& c, float a, float b);
+template <> __device__ __forceinline__ void pmma<32>(f32x16& c, float a, float b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void pmma<16>(f32x4& c, float a, float b) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// MT: MFMA tile edge (32: 32x32x2, 16: 16x16x4); CO_T = MT output channels per workgroup slice;
+// CI_T input channels per slice; KS x KS taps, stride S; TW tile width.
+template <int MT, int CI_T, int KS, int S, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams p) {
+  constexpr int CO_T = MT;
+  constexpr int PH = (PT_TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+  constexpr int KSTEP = (MT == 32) ? 2 : 4;            // pixels per MFMA
+  constexpr int NCOL = KS * KS * CI_T;                 // (tap, ci) columns
+  constexpr int NNT = (NCOL + MT - 1) / MT;            // column tiles per wave
+  // LDS row strides (floats).  X rows: consecutive pixels (the 2 or 4 lane groups of one MFMA operand)
+  // must land on disjoint banks: stride*S == MT (mod 32) for MT = 16; any 16-byte multiple for MT = 32.
+  constexpr int LXS = (CI_T >= 32) ? (MT == 16 ? CI_T + 16 : CI_T + 4) : CI_T;
+  constexpr int LYS = (MT == 32) ? CO_T + 4 : CO_T;
+  constexpr int XF = PH * PW * LXS, YF = PT_TH * TW * LYS;
+  constexpr int RED = 4 * MT * MT;
+  constexpr int LDS_F = (XF + YF > RED) ? XF + YF : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+  float* Xs = lds;
+  float* Ys = lds + XF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & (MT - 1);       // column / row inside the MFMA tile
+  const int lg = lane / MT;             // pixel group inside a k-step: 0..KSTEP-1
+  const int Cin = p.C0 + p.C1;
+  const int ci_slices = Cin / CI_T;
+  const int slice = blockIdx.y;
+  const int ci0 = (slice % ci_slices) * CI_T, co0 = (slice / ci_slices) * CO_T;
+  const bool from0 = ci0 < p.C0;
+  const int Cs = from0 ? p.C0 : p.C1;
+  const int sh = from0 ? p.shift0 : 0;
+  const int Hs = from0 ? p.H0s : p.Hv;
+  const int Ws = from0 ? p.W0s : p.Wv;
+  const int cl0 = from0 ? ci0 : ci0 - p.C0;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = from0 ? make_rsrc(p.src0, p.src0_bytes) : make_rsrc(p.src1, p.src1_bytes);
+
+  // per-lane column offsets into the patch for the small-channel (stem) case
+  int loff[(CI_T >= MT) ? 1 : NNT];
+  if (CI_T < MT) {
+#pragma unroll
+    for (int j = 0; j < NNT; ++j) {
+      const int n = j * MT + lc;
+      int tap = n / CI_T;
+      const int c = n - tap * CI_T;
+      if (tap >= KS * KS) tap = KS * KS - 1;  // padding columns: any valid address, never stored
+      const int kh = tap / KS, kw = tap - kh * KS;
+      loff[(CI_T >= MT) ? 0 : j] = (kh * PW + kw) * LXS + c;
+    }
+  }
+
+  typename PAcc<MT>::T acc[NNT];
+#pragma unroll
+  for (int j = 0; j < NNT; ++j)
+#pragma unroll
+    for (int r = 0; r < PAcc<MT>::N; ++r) acc[j][r] = 0.f;
+
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + PT_TH - 1) / PT_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  constexpr int VX = CI_T / 4, VY = CO_T / 4;  // 16-byte vectors per pixel row
+
+  // staging: every load of a tile is issued into registers first (no load -> wait -> store chains),
+  // and the NEXT tile's loads are issued before the MFMA sweep of the current one.
+  constexpr int NVX = (PH * PW * VX + 255) / 256, NVY = (PT_TH * TW * VY + 255) / 256;
+  uint4 rxv[NVX], ryv[NVY];
+  auto issue_loads = [&](int t) {
+    const int b = t / (tiles_y * tiles_x);
+    const int tr = t - b * tiles_y * tiles_x;
+    const int oy0 = (tr / tiles_x) * PT_TH, ox0 = (tr % tiles_x) * TW;
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VX, cv = v - pix * VX;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = oy0 * S - p.pad + py, ix = ox0 * S - p.pad + px;
+      const bool ok = v < PH * PW * VX && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+      const int gp = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
+      rxv[i] = buf_load16(rx, ok ? (unsigned)(gp * Cs + cl0 + cv * 4) * 4u : BUF_OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VY, cv = v - pix * VY;
+      const int y = pix / TW, x = pix - y * TW;
+      const int oy = oy0 + y, ox = ox0 + x;
+      const int co = co0 + cv * 4;
+      const bool ok = v < PT_TH * TW * VY && oy < p.Ho && ox < p.Wo && co < p.Cout;
+      ryv[i] = buf_load16(rdy, ok ? (unsigned)(((b * p.Ho + oy) * p.Wo + ox) * p.Cout + co) * 4u : BUF_OOB);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VX, cv = v - pix * VX;
+      if (v < PH * PW * VX) *reinterpret_cast<uint4*>(&Xs[pix * LXS + cv * 4]) = rxv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VY, cv = v - pix * VY;
+      if (v < PT_TH * TW * VY) *reinterpret_cast<uint4*>(&Ys[pix * LYS + cv * 4]) = ryv[i];
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) issue_loads(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile's MFMA reads are done
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) issue_loads(t + gridDim.x);
+    // ---- all taps from LDS -----------------------------------------------------------------------
+#pragma unroll
+    for (int yy = 0; yy < PT_TH / 4; ++yy) {
+      const int y = wave * (PT_TH / 4) + yy;
+      const float* __restrict__ yrow = Ys + (y * TW + lg) * LYS + lc;
+      const float* __restrict__ xrow = Xs + ((y * S) * PW + lg * S) * LXS + ((CI_T >= MT) ? lc : 0);
+#pragma unroll
+      for (int xs = 0; xs < TW / KSTEP; ++xs) {
+        const float a = yrow[xs * KSTEP * LYS];
+        const float* __restrict__ xb = xrow + xs * KSTEP * S * LXS;
+#pragma unroll
+        for (int j = 0; j < NNT; ++j) {
+          float bv;
+          if (CI_T >= MT) {
+            constexpr int per_tap = CI_T / MT;   // column tiles per tap
+            const int tap = j / per_tap, cb = (j % per_tap) * MT;
+            const int kh = tap / KS, kw = tap % KS;
+            bv = xb[(kh * PW + kw) * LXS + cb];   // compile-time offset -> ds_read immediate
+          } else {
+            bv = xb[loff[(CI_T >= MT) ? 0 : j]];
+          }
+          pmma<MT>(acc[j], a, bv);
+        }
+      }
+    }
+  }
+
+  // ---- sum the four waves' partial accumulators, one column tile at a time -------------------------
+  const int taps = KS * KS;
+  float* __restrict__ slab = p.partial + (long)blockIdx.x * p.Cout * taps * Cin;
+  float* red = lds;
+#pragma unroll
+  for (int j = 0; j < NNT; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PAcc<MT>::N; ++r) {
+      // D[co][col]: col = lane % MT; MT=32: co = (r&3) + 8*(r>>2) + 4*(lane>>5); MT=16: co = 4*(lane>>4) + r
+      const int co_l = (MT == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * lg) : (4 * lg + r);
+      red[(wave * MT + co_l) * MT + lc] = acc[j][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * MT; e += 256) {
+      const float s = (red[e] + red[MT * MT + e]) + (red[2 * MT * MT + e] + red[3 * MT * MT + e]);
+      const int co = co0 + e / MT;
+      const int n = j * MT + (e % MT);
+      const int tap = n / CI_T, ci = ci0 + (n - tap * CI_T);
+      if (co < p.Cout && tap < taps) slab[((long)co * taps + tap) * Cin + ci] = s;
+    }
+  }
+}
+
+// variants: 1: 3x3 s1, <=16 out, 32-channel slices (decoder 4 conv1)   2: 3x3 s1, <=16 out, 16-channel slices
+//           3: 3x3 s1, 32-out slices, 32-channel slices (decoder 3)     4: 7x7 s2 stem, 4 (3+pad) channels
+int wgrad_patch_variant(const WgradParams& p) {
+  const int cin = p.C0 + p.C1;
+  if (p.KH != p.KW) return 0;
+  if (p.KH == 3 && p.stride == 1 && p.pad == 1) {
+    if (p.Cout <= 16 && cin % 32 == 0 && cin <= 64 && (p.C1 == 0 || p.C0 % 32 == 0)) return 1;
+    if (p.Cout <= 16 && cin == 16) return 2;
+    if (p.Cout == 32 && cin % 32 == 0 && cin <= 128 && (p.C1 == 0 || p.C0 % 32 == 0)) return 3;
+  }
+  if (p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 4 && p.C1 == 0 && p.Cout % 32 == 0 && p.Cout <= 64)
+    return 4;
+  return 0;
+}
+
+void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
+  const int cin = p.C0 + p.C1;
+  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : 4;
+  const int co_t = (variant == 3 || variant == 4) ? 32 : 16;
+  const int slices = (cin / ci_t) * cdiv(p.Cout, co_t);
+  const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
+  int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  *gx = g;
+  *gy = slices;
+}
+
+int wgrad_patch_launch(const WgradParams& p, int variant, hipStream_t stream) {
+  int gx, gy;
+  wgrad_patch_grid(p, variant, &gx, &gy);
+  D3F_CHECK(p.splits == gx, "wgrad patch: params were not planned (splits %d vs %d)", p.splits, gx);
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((conv_wgrad_patch_kernel<16, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_patch_kernel<16, 16, 3, 1, 16>), grid, block, 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((conv_wgrad_patch_kernel<32, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((conv_wgrad_patch_kernel<32, 4, 7, 2, 16>), grid, block, 0, stream, p); break;
+    default: return set_error(-1, "wgrad patch: bad variant %d", variant);
+  }
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace d3f

@@ -90,6 +90,8 @@ CASES = [
     (2, 16, 16, 32, 0, 16, 3, 1, 1, True),       # decoder block 4 conv1 (256x16 tile, 16x16 MFMA)
     (2, 16, 16, 16, 0, 16, 3, 1, 1, False),      # small-channel K path
     (1, 32, 32, 128, 64, 64, 3, 1, 1, True),     # decoder block 2
+    (2, 24, 40, 16, 0, 3, 3, 1, 1, False),       # head shape (3 outputs), ragged 8x16 patch tiles
+    (1, 24, 40, 64, 64, 32, 3, 1, 1, True),      # decoder 3 conv1 with ragged patch tiles
 ]
 
 
