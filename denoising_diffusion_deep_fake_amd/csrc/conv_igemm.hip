@@ -18,51 +18,78 @@
 // (register-staged prefetch, one LDS buffer, two barriers per k-tile).
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace d3f {
 
 template <typename T, int MT> struct Mma;
+// run(c, a, b, after): `after()` is called behind every MFMA instruction -- the hook the main loop uses
+// to place pieces of the next tile's address arithmetic / loads in the MFMA's shadow.
 template <> struct Mma<float, 32> {
   using Acc = f32x16;
   static constexpr int NREG = 16;
-  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b) {
+  static constexpr int NINST = 4;
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b, F&& after) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    after();
   }
 };
 template <> struct Mma<float, 16> {
   using Acc = f32x4;
   static constexpr int NREG = 4;
-  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b) {
+  static constexpr int NINST = 4;
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b, F&& after) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    after();
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    after();
   }
 };
 template <> struct Mma<bf16_t, 32> {
   using Acc = f32x16;
   static constexpr int NREG = 16;
-  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b) {
+  static constexpr int NINST = 1;
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b, F&& after) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
                                                 *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    after();
   }
 };
 template <> struct Mma<bf16_t, 16> {
   using Acc = f32x4;
   static constexpr int NREG = 4;
-  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b) {
+  static constexpr int NINST = 1;
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4& a, const uint4& b, F&& after) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
                                                 *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    after();
   }
 };
 
 constexpr int LDS_ROW = 36;  // dwords per LDS row: 128 B of data + 16 B pad
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC>
+// SMALLC: Cin < one k-row (taps decoded per lane).  FAST: plain gather (one source, no up-sampling /
+// zero insertion, <= 32 taps): per-row base offset + tap-validity bitmask are computed once, so a
+// k-tile costs ~4 VALU per gathered vector.  This matters because the f32 MFMA runs at the f32 VALU
+// rate and VALU time ADDS to it (microbenchmark in profiles/README.md): VALU per MFMA is the lever.
+template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int VE = Elem<T>::VE, BKE = Elem<T>::BKE;
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / MT, FN = TN / MT;
@@ -74,9 +101,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   using M_ = Mma<T, MT>;
   using Acc = typename M_::Acc;
 
-  __shared__ __attribute__((aligned(16))) uint32_t lds[(BM + BN) * LDS_ROW];
-  uint32_t* As = lds;
-  uint32_t* Bs = lds + BM * LDS_ROW;
+  // two LDS stages (tile t is read by the MFMAs while tile t+1 is written and tile t+2 is loaded),
+  // except for the 256-row tiles of the narrow layers: 2 x 41 KB would leave one workgroup per CU
+  constexpr bool DB = BM < 256;
+  constexpr int NSTAGE = DB ? 2 : 1;
+  constexpr int STAGE = (BM + BN) * LDS_ROW;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -106,6 +136,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         iy0[i] = -(1 << 24);  // fails every bounds test
         ix0[i] = 0;
       }
+    }
+  }
+
+  // FAST mode: byte offset of (row, tap 0, this lane's chunk) and a bit per tap "inside the image"
+  unsigned rowoff[NVA], vmask[NVA];
+  if (FAST) {
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const bool rowok = iy0[i] > -(1 << 23);
+      rowoff[i] = (unsigned)(((bidx[i] * p.Hv + iy0[i]) * p.Wv + ix0[i]) * p.C0 + chunk * VE) * (unsigned)sizeof(T);
+      unsigned mk = 0;
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw) {
+          const int iy = iy0[i] + kh, ix = ix0[i] + kw;
+          const unsigned ok = (unsigned)(rowok & ((unsigned)iy < (unsigned)p.Hv) & ((unsigned)ix < (unsigned)p.Wv));
+          mk |= ok << (kh * p.KW + kw);
+        }
+      vmask[i] = mk;
     }
   }
 
@@ -147,71 +195,103 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
 
   uint4 ra[NVA], rb[NVB];
-  auto load_tile = [&](int kt) {
-    int kh, kw, c;
-    bool tapvalid = true;
-    bool from0 = true;  // wave-uniform by construction (plan checks C0 % BKE == 0 when C1 > 0)
+  // the load of one k-tile = a wave-uniform setup + (NVA + NVB) independent per-vector pieces
+  // (address arithmetic + one buffer load each), so the main loop can emit the pieces one by one
+  // between MFMAs.
+  struct TileCtx {
+    int kh, kw, c, kt;
+    int tapvalid, parity_mask, Cs, sh, Hs, Ws;
+    unsigned tapdelta, tapbit;  // FAST mode (wave-uniform)
+    bool from0;
+  };
+  auto tile_setup = [&](int kt) {
+    TileCtx x;
+    x.kt = kt;
+    x.tapvalid = 1;
+    x.from0 = true;
     if (SMALLC) {
       const int kk = kt * BKE + chunk * VE;
       const int tap = kk / Cin;
-      c = kk - tap * Cin;
-      kh = tap / p.KW;
-      kw = tap - kh * p.KW;
-      tapvalid = tap < p.KH * p.KW;
+      x.c = kk - tap * Cin;
+      x.kh = tap / p.KW;
+      x.kw = tap - x.kh * p.KW;
+      x.tapvalid = tap < p.KH * p.KW ? 1 : 0;
     } else {
-      kh = t_kh;
-      kw = t_kw;
-      from0 = t_c < p.C0;
-      c = (from0 ? t_c : t_c - p.C0) + chunk * VE;
+      x.kh = t_kh;
+      x.kw = t_kw;
+      x.from0 = t_c < p.C0;
+      x.c = (x.from0 ? t_c : t_c - p.C0) + chunk * VE;
+      x.tapdelta = (unsigned)((t_kh * p.Wv + t_kw) * p.C0 + t_c) * (unsigned)sizeof(T);
+      x.tapbit = (unsigned)(t_kh * p.KW + t_kw);
+      // branch-free advance (keeps the steady-state loop body one basic block)
       t_c += BKE;
-      if (t_c >= Cin) {
-        t_c = 0;
-        if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
-      }
+      const int wrap_c = t_c >= Cin ? 1 : 0;
+      t_c = wrap_c ? 0 : t_c;
+      t_kw += wrap_c;
+      const int wrap_w = t_kw == p.KW ? 1 : 0;
+      t_kw = wrap_w ? 0 : t_kw;
+      t_kh += wrap_w;
     }
-    const int Cs = from0 ? p.C0 : p.C1;
-    const int sh = from0 ? p.shift0 : 0;
-    const int Hs = from0 ? p.H0s : p.Hv;
-    const int Ws = from0 ? p.W0s : p.Wv;
-    const bool parity = from0 && p.zi;
-    unsigned off[NVA];
-#pragma unroll
-    for (int i = 0; i < NVA; ++i) {
-      const int iy = iy0[i] + kh, ix = ix0[i] + kw;
-      bool v = tapvalid && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
-      if (parity) v = v && (((iy | ix) & 1) == 0);
-      const int pix = (bidx[i] * Hs + (iy >> sh)) * Ws + (ix >> sh);
-      off[i] = v ? (unsigned)(pix * Cs + c) * (unsigned)sizeof(T) : BUF_OOB;
-    }
-    if (from0) {
-#pragma unroll
-      for (int i = 0; i < NVA; ++i) ra[i] = buf_load16(r0, off[i]);
+    x.Cs = x.from0 ? p.C0 : p.C1;
+    x.sh = x.from0 ? p.shift0 : 0;
+    x.Hs = x.from0 ? p.H0s : p.Hv;
+    x.Ws = x.from0 ? p.W0s : p.Wv;
+    x.parity_mask = (x.from0 && p.zi) ? 1 : 0;  // zero insertion: only even (iy, ix) exist
+    return x;
+  };
+  // piece q < NVA: activation row q; q >= NVA: weight row q - NVA.  Bitwise & (not &&) and an
+  // unconditional offset: short-circuit evaluation would put every row's arithmetic under its own
+  // divergent branch and split the loop body into many basic blocks.
+  auto tile_piece = [&](const TileCtx& x, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < NVA && FAST) {
+      const unsigned o = rowoff[q] + x.tapdelta;
+      ra[q] = buf_load16(r0, ((vmask[q] >> x.tapbit) & 1u) ? o : BUF_OOB);
+    } else if constexpr (q < NVA) {
+      const int iy = iy0[q] + x.kh, ix = ix0[q] + x.kw;
+      const int v = x.tapvalid & (int)((unsigned)iy < (unsigned)p.Hv) & (int)((unsigned)ix < (unsigned)p.Wv) &
+                    (int)(((iy | ix) & x.parity_mask) == 0);
+      const int pix = (bidx[q] * x.Hs + (iy >> x.sh)) * x.Ws + (ix >> x.sh);
+      const unsigned o = (unsigned)(pix * x.Cs + x.c) * (unsigned)sizeof(T);
+      const __amdgpu_buffer_rsrc_t rs = x.from0 ? r0 : r1;  // wave-uniform: scalar select, no branch
+      ra[q] = buf_load16(rs, v ? o : BUF_OOB);
     } else {
-#pragma unroll
-      for (int i = 0; i < NVA; ++i) ra[i] = buf_load16(r1, off[i]);
+      // an out-of-range row keeps bit 31 set after the add (descriptors cover < 2 GiB): no select
+      constexpr int j = q - NVA;
+      rb[j] = buf_load16(rw, woff[j] + (unsigned)(x.kt * BKE) * (unsigned)sizeof(T));
     }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j)
-      rb[j] = buf_load16(rw, woff[j] == BUF_OOB ? BUF_OOB : woff[j] + (unsigned)(kt * BKE) * (unsigned)sizeof(T));
+  };
+  auto load_tile = [&](int kt) {
+    const TileCtx x = tile_setup(kt);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (tile_piece(x, std::integral_constant<int, Q>{}), ...);
+    }(std::make_integer_sequence<int, NVA + NVB>{});
   };
 
-  load_tile(kt_begin);
   const int fr = (MT == 32) ? (lane & 31) : (lane & 15);
   const int fq = (MT == 32) ? (lane >> 5) : (lane >> 4);
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    // stage the prefetched tile
+  auto stage = [&](int buf) {
+    uint32_t* As = lds + buf * STAGE;
+    uint32_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
     for (int i = 0; i < NVA; ++i)
       *reinterpret_cast<uint4*>(&As[(rbase + 32 * i) * LDS_ROW + chunk * 4]) = ra[i];
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
       const int row = rbase + 32 * j;
-      if (row < BN) *reinterpret_cast<uint4*>(&Bs[row * LDS_ROW + chunk * 4]) = rb[j];
+      if (BN >= 32 || row < BN) *reinterpret_cast<uint4*>(&Bs[row * LDS_ROW + chunk * 4]) = rb[j];
     }
-    __syncthreads();
-    if (kt + 1 < kt_end) load_tile(kt + 1);
+  };
 
+  // Software pipeline, ONE barrier per k-tile: in iteration t the registers hold tile t+1 (loaded
+  // during iteration t-1); they are written to the other LDS stage, the loads of tile t+2 are issued,
+  // and the MFMAs run on tile t -- all inside one barrier interval, so the staging writes, the
+  // address generation and the load issue sit in the MFMAs' shadow instead of in front of them.
+  // compute(buf, hook): hook(n) runs behind the n-th MFMA instruction of the k-tile
+  auto compute = [&](int buf, auto&& hook) {
+    const uint32_t* As = lds + buf * STAGE;
+    const uint32_t* Bs = As + BM * LDS_ROW;
+    int n = 0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int ch = (MT == 32) ? (2 * s + fq) : (4 * s + fq);
@@ -225,10 +305,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) M_::run(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < FN; ++j) M_::run(acc[i][j], a[i], b[j], [&]() { hook(n++); });
     }
+  };
+  auto no_hook = [](int) {};
+
+  constexpr int NMFMA = NS * FM * FN * M_::NINST;
+  constexpr int NPIECE = NVA + NVB;
+  constexpr int EVERY = (NMFMA / NPIECE) > 0 ? (NMFMA / NPIECE) : 1;
+  // emits the load pieces of tile context x behind the MFMAs of compute(buf)
+  auto compute_and_load = [&](int buf, const TileCtx& x) {
+    compute(buf, [&](int n) {
+      // n is a compile-time constant after unrolling: piece n/EVERY goes behind MFMA n
+      [&]<int... Q>(std::integer_sequence<int, Q...>) {
+        ((n == Q * EVERY ? (tile_piece(x, std::integral_constant<int, Q>{}), 0) : 0), ...);
+      }(std::make_integer_sequence<int, NPIECE>{});
+    });
+    // pieces that did not get a slot (more pieces than MFMAs)
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      ((Q * EVERY >= NMFMA ? (tile_piece(x, std::integral_constant<int, Q>{}), 0) : 0), ...);
+    }(std::make_integer_sequence<int, NPIECE>{});
+  };
+
+  if constexpr (!DB) {
+    // single LDS stage: stage -> barrier -> (next tile's loads behind the MFMAs) -> barrier
+    load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      stage(0);
+      __syncthreads();
+      if (kt + 1 < kt_end) {
+        const TileCtx x = tile_setup(kt + 1);
+        compute_and_load(0, x);
+      } else {
+        compute(0, no_hook);
+      }
+      __syncthreads();
+    }
+  } else {
+  load_tile(kt_begin);
+  stage(0);
+  if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1);
+  __syncthreads();
+  int kt = kt_begin;
+  // steady state: one basic block per k-tile.  A wave issues in order and an f32 MFMA keeps the matrix
+  // pipe busy for 32-64 cycles, so the next tile's address arithmetic and buffer loads are emitted
+  // piece by piece BEHIND individual MFMAs (in source order) instead of in front of the MFMA block.
+  for (; kt + 2 < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    stage(cur ^ 1);
+    const TileCtx x = tile_setup(kt + 2);
+    compute_and_load(cur, x);
     __syncthreads();
   }
+  for (; kt < kt_end; ++kt) {  // last two tiles: nothing left to load
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) stage(cur ^ 1);
+    compute(cur, no_hook);
+    __syncthreads();
+  }
+  }  // DB
 
   // ---- epilogue ----------------------------------------------------------------------
   // accumulator element (i, j, r) of this lane = out[m][n] with
@@ -237,115 +372,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int n_l = fr;
   auto m_local = [&](int r) { return (MT == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * fq) : (4 * fq + r); };
 
-  if (p.splitk > 1) {
-    float* __restrict__ slab = p.partial + (long)blockIdx.y * p.M * p.Cout;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * MT + n_l;
-#pragma unroll
-        for (int r = 0; r < M_::NREG; ++r) {
-          const int m = m0 + wm * TM + i * MT + m_local(r);
-          if (m < p.M && n < p.Cout) slab[(long)m * p.Cout + n] = acc[i][j][r];
-        }
-      }
-  } else if (p.mode == CONV_RAW_STATS) {
-    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
-    float s1[FN], s2[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * MT + n_l;
-#pragma unroll
-        for (int r = 0; r < M_::NREG; ++r) {
-          const int m = m0 + wm * TM + i * MT + m_local(r);
-          const float v = acc[i][j][r];
-          s1[j] += v;
-          s2[j] += v * v;
-          if (m < p.M && n < p.Cout) out[(long)m * p.Cout + n] = from_f32<T>(v);
-        }
-      }
-    if (p.stats != nullptr) {
-      // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
-      float* red = reinterpret_cast<float*>(lds);  // [WGM][BN][2]; k-loop ended with a barrier
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        float a1 = s1[j], a2 = s2[j];
-        a1 += __shfl_xor(a1, 32);
-        a2 += __shfl_xor(a2, 32);
-        if (MT == 16) {
-          a1 += __shfl_xor(a1, 16);
-          a2 += __shfl_xor(a2, 16);
-        }
-        if (lane < MT) {
-          const int col = wn * TN + j * MT + lane;
-          red[(wm * BN + col) * 2 + 0] = a1;
-          red[(wm * BN + col) * 2 + 1] = a2;
-        }
-      }
-      __syncthreads();
-      if (tid < BN) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WGM; ++w) {
-          a1 += red[(w * BN + tid) * 2 + 0];
-          a2 += red[(w * BN + tid) * 2 + 1];
-        }
-        const int n = n0 + tid;
-        if (n < p.CoutPad) {
-          p.stats[((long)tile_m * p.CoutPad + n) * 2 + 0] = a1;
-          p.stats[((long)tile_m * p.CoutPad + n) * 2 + 1] = a2;
-        }
-      }
-    }
-  } else if (p.mode == CONV_EVAL_FUSED) {
-    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * MT + n_l;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale[n], sf = p.shift[n];
-#pragma unroll
-        for (int r = 0; r < M_::NREG; ++r) {
-          const int m = m0 + wm * TM + i * MT + m_local(r);
-          if (m >= p.M) continue;
-          float v = acc[i][j][r] * sc + sf;
-          if (res != nullptr) v += to_f32<T>(res[(long)m * p.Cout + n]);
-          if (p.relu) v = fmaxf(v, 0.f);
-          out[(long)m * p.Cout + n] = from_f32<T>(v);
-        }
-      }
-  } else if (p.mode == CONV_DGRAD) {
-    T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
-    T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
-    const int c0 = p.out_c0, c1 = p.Cout - p.out_c0;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * MT + n_l;
-        if (n >= p.Cout) continue;
-        const bool first = n < c0;
-        T* __restrict__ dst = first ? o0 + n : o1 + (n - c0);
-        const int ld = first ? c0 : c1;
-        const bool accum = first ? p.acc0 : p.acc1;
-#pragma unroll
-        for (int r = 0; r < M_::NREG; ++r) {
-          const int m = m0 + wm * TM + i * MT + m_local(r);
-          if (m >= p.M) continue;
-          float v = acc[i][j][r];
-          if (accum) v += to_f32<T>(dst[(long)m * ld]);
-          dst[(long)m * ld] = from_f32<T>(v);
-        }
-      }
-  } else {  // CONV_HEAD_NCHW: + bias, fp32 NCHW
+  if (p.mode == CONV_HEAD_NCHW && p.splitk == 1) {  // + bias, fp32 NCHW (3 output channels: scalar path)
     float* __restrict__ out = reinterpret_cast<float*>(p.out0);
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -364,6 +391,139 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
           out[((long)b * p.Cout + n) * HoWo + pix] = acc[i][j][r] + bias;
         }
       }
+    return;
+  }
+
+  // Everything else goes through LDS: the C tile is staged as [BM][BN (+4)] f32 (the k-loop ended
+  // with a barrier, both stages are free), then written out as 16-byte vectors along the channel
+  // dimension -- 4x fewer store instructions than one dword per accumulator register, and the
+  // per-channel statistics are column sums of the staged tile.
+  constexpr int LDC = BN + 4;
+  static_assert(BM * LDC <= NSTAGE * STAGE, "C tile must fit in the LDS stages");
+  float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < M_::NREG; ++r)
+        Cs[(wm * TM + i * MT + m_local(r)) * LDC + wn * TN + j * MT + n_l] = acc[i][j][r];
+  __syncthreads();
+
+  constexpr int VN = BN / 4;                 // 16-byte vectors per tile row
+  constexpr int NVEC = BM * VN / 256;        // vectors per thread
+  const int cv = tid % VN, rv0 = tid / VN;   // this thread's vector column / first row
+  constexpr int RSTEP = 256 / VN;
+  const int n = n0 + cv * 4;
+  const bool n_ok = n < p.Cout;              // Cout is a multiple of 4 on every vector path (plan)
+
+  if (p.splitk > 1) {
+    float* __restrict__ slab = p.partial + (long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP, m = m0 + row;
+      if (n_ok && m < p.M)
+        *reinterpret_cast<float4*>(slab + (long)m * p.Cout + n) = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+    }
+    return;
+  }
+
+  auto store4 = [&](T* dst, float4 v) {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+      w.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+      *reinterpret_cast<uint2*>(dst) = w;
+    }
+  };
+  auto load4 = [&](const T* src) {
+    if constexpr (sizeof(T) == 4) {
+      return *reinterpret_cast<const float4*>(src);
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2*>(src);
+      return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u),
+                         __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+    }
+  };
+
+  if (p.mode == CONV_RAW_STATS) {
+    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP, m = m0 + row;
+      if (n_ok && m < p.M) store4(out + (long)m * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
+    }
+    if (p.stats != nullptr) {
+      // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
+      constexpr int NG = 256 / BN;  // row groups
+      const int col = tid % BN, rg = tid / BN;
+      float s1 = 0.f, s2 = 0.f;
+      for (int row = rg; row < BM; row += NG) {
+        const float v = Cs[row * LDC + col];
+        s1 += v;
+        s2 += v * v;
+      }
+      __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
+      float* red = reinterpret_cast<float*>(lds);
+      red[(rg * BN + col) * 2 + 0] = s1;
+      red[(rg * BN + col) * 2 + 1] = s2;
+      __syncthreads();
+      if (tid < BN) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          a1 += red[(g * BN + tid) * 2 + 0];
+          a2 += red[(g * BN + tid) * 2 + 1];
+        }
+        const int nn = n0 + tid;
+        if (nn < p.CoutPad) {
+          p.stats[((long)tile_m * p.CoutPad + nn) * 2 + 0] = a1;
+          p.stats[((long)tile_m * p.CoutPad + nn) * 2 + 1] = a2;
+        }
+      }
+    }
+  } else if (p.mode == CONV_EVAL_FUSED) {
+    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+    if (n_ok) {
+      const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+      for (int i = 0; i < NVEC; ++i) {
+        const int row = rv0 + i * RSTEP, m = m0 + row;
+        if (m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+        v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+        if (res != nullptr) {
+          const float4 rr = load4(res + (long)m * p.Cout + n);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        store4(out + (long)m * p.Cout + n, v);
+      }
+    }
+  } else if (p.mode == CONV_DGRAD) {
+    T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
+    T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
+    if (n_ok) {
+      const bool first = n < p.out_c0;  // out_c0 is a multiple of 4 (plan)
+      T* __restrict__ base = first ? o0 + n : o1 + (n - p.out_c0);
+      const int ld = first ? p.out_c0 : p.Cout - p.out_c0;
+      const bool accum = first ? p.acc0 : p.acc1;
+#pragma unroll
+      for (int i = 0; i < NVEC; ++i) {
+        const int row = rv0 + i * RSTEP, m = m0 + row;
+        if (m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+        T* dst = base + (long)m * ld;
+        if (accum) {
+          const float4 o = load4(dst);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        store4(dst, v);
+      }
+    }
   }
 }
 
@@ -439,8 +599,23 @@ static bool is_small_c(const ConvParams& p, int dtype) {
   return ((p.C0 + p.C1) % bke) != 0;
 }
 
+// tuning knob (debug): D3F_FORCE_TILE="BM,BN,SK" overrides the heuristics for regular (non small-C) layers
+static bool forced_tile(int* bm, int* bn, int* sk) {
+  static int v[3] = {0, 0, 0};
+  static bool init = false, on = false;
+  if (!init) {
+    init = true;
+    const char* e = getenv("D3F_FORCE_TILE");
+    on = e != nullptr && sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3;
+  }
+  *bm = v[0]; *bn = v[1]; *sk = v[2];
+  return on;
+}
+
 static ConvTile pick_tile(const ConvParams& p) {
   const int co = p.Cout;
+  int fbm, fbn, fsk;
+  if (forced_tile(&fbm, &fbn, &fsk) && co >= 64) return {fbm, fbn};
   if (co <= 16) return {256, 16};
   if (co <= 32) return {256, 32};
   // prefer the biggest tile that still gives >= 2 blocks per CU; small problems fall to 64x64
@@ -473,6 +648,9 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "conv: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "conv: M");
   D3F_CHECK(p.CoutPad >= p.Cout, "conv: CoutPad");
+  D3F_CHECK(p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0, "conv: Cout=%d must be a multiple of 4 (vector epilogue)", p.Cout);
+  D3F_CHECK(p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0, "conv: out_c0=%d must be a multiple of 4", p.out_c0);
+  D3F_CHECK(p.mode != CONV_HEAD_NCHW || !allow_splitk || true, "unreachable");
   D3F_CHECK(p.C1 == 0 || (p.C0 % bke) == 0, "conv: C0=%d must be a multiple of %d when a second source is concatenated", p.C0, bke);
   const long es = dtype == D3F_F32 ? 4 : 2;
   const long b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es, b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
@@ -489,12 +667,16 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   const int nk = p.Kpad / bke;
   const int vc = p.Cout / 4;
   static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob
-  if (allow_splitk && !no_splitk && !is_small_c(p, dtype) && base < 384 && (p.Cout % 4) == 0 && vc <= 256 &&
+  int f0, f1, f2;
+  const bool forced = forced_tile(&f0, &f1, &f2);
+  if (allow_splitk && !no_splitk && !is_small_c(p, dtype) && (base < 384 || forced) && (p.Cout % 4) == 0 && vc <= 256 &&
       (256 % vc) == 0 && (p.mode == CONV_RAW_STATS || p.mode == CONV_DGRAD) &&
       (p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0)) {
     int sk = (int)((640 + base - 1) / base);
     while (sk > 1 && nk / sk < 6) --sk;  // keep >= 6 k-tiles per slice
     if (sk > 8) sk = 8;
+    int fbm, fbn, fsk;
+    if (forced_tile(&fbm, &fbn, &fsk)) sk = fsk;
     if (sk > 1) {
       p.splitk = sk;
       p.stat_rows = cdiv(p.M, SK_ROWS);
@@ -506,10 +688,14 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
 template <typename T, int BM, int BN, int WGM, int WGN, int MT>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk), block(256);
+  static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
+  const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
   if (smallc)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true, false>), grid, block, 0, stream, p);
+  else if (fast)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, true>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, false>), grid, block, 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -530,6 +716,13 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const bool smallc = is_small_c(p, dtype);
   ConvParams q = p;
   if (q.partial == nullptr) q.splitk = 1;
+  // timing-only ablation (results are wrong): zero-record descriptors make every buffer load return
+  // zeros at once while the instruction stream, waits and barriers stay identical
+  static const char* ablate = getenv("D3F_ABLATE_LOADS");
+  if (ablate != nullptr) {
+    if (ablate[0] == 'a' || ablate[0] == 'b') q.src0_bytes = q.src1_bytes = 0;  // activations
+    if (ablate[0] == 'w' || ablate[0] == 'b') q.w_bytes = 0;                    // weights
+  }
   D3F_CHECK(q.splitk == 1 || q.stat_rows == cdiv(q.M, SK_ROWS), "conv: split-K params were not planned");
   const bool prof = prof_enabled();
   if (prof) prof_begin(q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD, q.flops, stream);
