@@ -1,0 +1,176 @@
+"""`d3f.train_deep_fake.lit_module.LitModule` on the HIP hot path.
+
+Mirrors d3f/train_deep_fake/lit_module.py:30-300: two U-Nets (`model_a`, `model_b`), two Adam
+optimisers alternated by `optimizer_idx`, `mode: "denoise"` (noisy real -> real) or `mode: "swap"`
+(EMA teacher of the OTHER domain renders a fake, the student denoises the noised fake back to the
+real image), and the single-frame inference entry `predict_fake`.  Same hyper-parameter keys as
+denoise_config.yml / swap_config.yml; extra optional keys: `synthetic`, `image_size`, `precision`.
+
+Reference quirks kept on purpose: the dataloaders receive `mean_x` as BOTH
+mean and std (lit_module.py:75-76); `predict_fake("a")` uses model_a with B's mean/std (:253-257);
+de-normalisation truncates with `.int()` BEFORE clamping (:293-294).
+"""
+from datetime import timedelta
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim.lr_scheduler as schedulers
+from torch.utils.data import DataLoader
+
+from .. import ops
+from ..dataset.image_dataset import ImageDataset, NormalizeToTensor, SyntheticFaceDataset
+from ..lightning import LightningModule
+from ..loss_functions import MseStructuralSimilarityLoss
+from ..optim import EMA, FusedAdam
+from ..trainer import LearningRateMonitor, ModelCheckpoint
+from ..unet import Unet
+
+
+class LitModule(LightningModule):
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.save_hyperparameters()
+        self.model_a = self.create_model_instance()
+        self.model_b = self.create_model_instance()
+        self.ema_model_a = self.create_ema_model(self.model_a)
+        self.ema_model_b = self.create_ema_model(self.model_b)
+        self.criterion = MseStructuralSimilarityLoss(-1.0, 1.0)
+
+    def create_model_instance(self):
+        p = self.hparams
+        return Unet(
+            encoder_name=p["encoder_name"],
+            encoder_weights=None,
+            in_channels=3,
+            classes=3,
+            activation=None,
+            compute_dtype=p.get("precision", "f32"),
+        )
+
+    def create_ema_model(self, model):
+        p = self.hparams
+        if p.mode == "swap":
+            return EMA(
+                model,
+                beta=p.ema_beta,
+                update_every=p.ema_update_every,
+                include_online_model=False,
+            )
+        return None
+
+    def train_dataloader(self):
+        p = self.hparams
+        dataloader_a = self.create_dataloader(p.get("data_path_a"), p.mean_a, p.mean_a)
+        dataloader_b = self.create_dataloader(p.get("data_path_b"), p.mean_b, p.mean_b)
+        return {"a": dataloader_a, "b": dataloader_b}
+
+    def create_dataloader(self, path, mean, std):
+        p = self.hparams
+        if p.get("synthetic", False) or path is None:
+            dataset = SyntheticFaceDataset(p.get("synthetic_length", 8 * p.batch_size), p.get("image_size", 256),
+                                           seed=1234 + (hash(str(path)) % 1000))
+        else:
+            dataset = ImageDataset(path, transform=self.create_augmentation_sequence(mean, std))
+        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=p.get("num_workers", 0),
+                          shuffle=True, drop_last=True)
+
+    def create_augmentation_sequence(self, mean, std):
+        # albumentations Normalize + ToTensorV2; the random ShiftScaleRotate(p=0.7) of the reference is
+        # augmentation noise outside the numerics contract
+        return NormalizeToTensor(mean, std)
+
+    def configure_optimizers(self):
+        p = self.hparams
+        b1, b2 = p.adam_b1, p.adam_b2
+        optimizer_a = FusedAdam(self.model_a.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_a)
+        optimizer_b = FusedAdam(self.model_b.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_b)
+        scheduler_a = schedulers.CosineAnnealingLR(optimizer_a, T_max=p.cosine_scheduler_max_epoch)
+        scheduler_b = schedulers.CosineAnnealingLR(optimizer_b, T_max=p.cosine_scheduler_max_epoch)
+        return [optimizer_a, optimizer_b], [scheduler_a, scheduler_b]
+
+    def configure_callbacks(self):
+        return [
+            LearningRateMonitor(logging_interval="step"),
+            ModelCheckpoint(save_top_k=8, monitor="epoch", mode="max", train_time_interval=timedelta(hours=2)),
+            ModelCheckpoint(filename="last", save_on_train_epoch_end=True),
+        ]
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        batch_a = batch["a"]["image"]
+        batch_b = batch["b"]["image"]
+        if optimizer_idx == 0:
+            loss = self.training_step_for_one_model("a", batch_a, self.model_a, self.ema_model_b)
+        if optimizer_idx == 1:
+            loss = self.training_step_for_one_model("b", batch_b, self.model_b, self.ema_model_a)
+        self.log("epoch", float(self.current_epoch))
+        return loss
+
+    def training_step_for_one_model(self, name, real, real_model, fake_model):
+        p = self.hparams
+        if p.mode == "denoise":
+            return self.training_denoise_step_for_one_model(name, real, real_model)
+        elif p.mode == "swap":
+            return self.training_swap_step_for_one_model(name, real, real_model, fake_model)
+        raise ValueError(f"unknown mode {p.mode!r}")
+
+    def training_denoise_step_for_one_model(self, name, real, real_model):
+        with torch.no_grad():
+            noisy_real = self.blend_random_amount_of_noise_with_each_sample(real)
+        real_prediction = real_model(noisy_real)
+        loss = self.criterion(real_prediction, real)
+        self.log(f"loss_denoise/train_{name}", loss)
+        return loss
+
+    def training_swap_step_for_one_model(self, name, real, real_model, fake_model):
+        fake_model.update()
+        with torch.no_grad():
+            fake = fake_model(real)  # train-mode BatchNorm: the EMA wrapper is a registered sub-module
+            swap_diff = nn.functional.mse_loss(real, fake)
+            noisy_fake = self.blend_random_amount_of_noise_with_each_sample(fake)
+        real_prediction = real_model(noisy_fake)
+        loss = self.criterion(real_prediction, real)
+        self.log(f"swap_difference/{name}", swap_diff)
+        self.log(f"loss_swap/train_{name}", loss)
+        return loss
+
+    @torch.no_grad()
+    def blend_random_amount_of_noise_with_each_sample(self, batch):
+        p = self.hparams
+        noise = torch.randn_like(batch)  # reference RNG order: randn_like first, then rand
+        y = torch.rand(size=(batch.shape[0], 1, 1, 1), device=batch.device)
+        return ops.noise_blend(batch, noise, y.reshape(-1), p.noise_exponential_sampling_lambda)
+
+    # ---- single-frame inference (script_tools/put_video_through_fake_model.py:117) ----------------
+    def predict_fake(self, real_bgr, model_a_or_b):
+        p = self.hparams
+        if model_a_or_b == "a":
+            return self.predict_fake_for_single_frame(real_bgr, self.model_a, p.mean_b, p.std_b)
+        if model_a_or_b == "b":
+            return self.predict_fake_for_single_frame(real_bgr, self.model_b, p.mean_a, p.std_a)
+
+    @torch.no_grad()
+    def predict_fake_for_single_frame(self, real_bgr, model, mean, std):
+        mean = torch.tensor(mean, device=self.device, dtype=torch.float32)
+        std = torch.tensor(std, device=self.device, dtype=torch.float32)
+        input_tensor = self.cv2_to_tensor_normalised(real_bgr, mean, std)
+        output_tensor = model(input_tensor)
+        return self.tensor_cv2_to_denormalised(output_tensor, mean, std)
+
+    def cv2_to_tensor_normalised(self, image_bgr, mean, std):
+        image_rgb = np.ascontiguousarray(image_bgr[:, :, ::-1])  # cv2.COLOR_BGR2RGB
+        tensor = torch.from_numpy(image_rgb).float().to(self.device)
+        tensor = tensor.permute(2, 0, 1)  # hwc to chw
+        tensor = tensor - mean.reshape(3, 1, 1) * 255
+        tensor = tensor / (std.reshape(3, 1, 1) * 255)
+        return tensor.unsqueeze(0).contiguous()
+
+    def tensor_cv2_to_denormalised(self, tensor, mean, std):
+        tensor = tensor.squeeze(0)
+        tensor = tensor * (std.reshape(3, 1, 1) * 255)
+        tensor = tensor + mean.reshape(3, 1, 1) * 255
+        tensor = tensor.permute(1, 2, 0)  # chw to hwc
+        tensor = tensor.int()
+        tensor = tensor.clamp(0, 255)
+        image_rgb = tensor.cpu().numpy().astype(np.uint8)
+        return np.ascontiguousarray(image_rgb[:, :, ::-1])  # cv2.COLOR_RGB2BGR

@@ -1,0 +1,258 @@
+"""Minimal training loop with the pytorch_lightning 1.x semantics the reference relies on
+ -- pytorch_lightning is not available on the MI355X image.
+
+  * `Trainer(max_epochs, callbacks, ...).fit(module, ckpt_path=None)`
+  * automatic optimisation with N optimisers: per batch, for optimizer_idx in 0..N-1:
+        toggle (only that optimiser's parameters keep requires_grad) -> zero_grad ->
+        training_step(batch, batch_idx[, optimizer_idx]) -> backward -> step -> untoggle;
+    `global_step` counts optimiser steps
+  * LR schedulers are stepped once per epoch
+  * dict of dataloaders -> CombinedLoader(mode="max_size_cycle")
+  * checkpoints are Lightning-style dicts {"epoch", "global_step", "state_dict",
+    "optimizer_states", "lr_schedulers", "hyper_parameters"} under
+    <default_root_dir>/version_N/checkpoints/
+Data parallel: one process per GPU (torch.distributed.run); gradients are all-reduced by
+distributed.DataParallel, overlapped with the backward pass.  `self.log` values stay on the device
+and are flushed to metrics.csv every `flush_every` steps (no per-step host sync).
+"""
+import inspect
+import itertools
+import os
+import time
+from pathlib import Path
+
+import torch
+
+from . import distributed as dist_utils
+
+
+class Callback:
+    def on_fit_start(self, trainer, module):
+        pass
+
+    def on_train_batch_end(self, trainer, module):
+        pass
+
+    def on_train_epoch_end(self, trainer, module):
+        pass
+
+
+class LearningRateMonitor(Callback):
+    def __init__(self, logging_interval="step"):
+        self.logging_interval = logging_interval
+
+    def on_train_batch_end(self, trainer, module):
+        for i, opt in enumerate(trainer.optimizers):
+            name = "lr-Adam" if len(trainer.optimizers) == 1 else f"lr-Adam-{i}" if i else "lr-Adam"
+            module._logged[name] = opt.param_groups[0]["lr"]
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, filename=None, save_top_k=1, monitor=None, mode="min", train_time_interval=None,
+                 save_on_train_epoch_end=None, dirpath=None):
+        self.filename, self.save_top_k, self.monitor, self.mode = filename, save_top_k, monitor, mode
+        self.train_time_interval = train_time_interval
+        self.save_on_train_epoch_end = save_on_train_epoch_end
+        self.dirpath = dirpath
+        self._last_time = time.monotonic()
+        self._saved = []
+
+    def _path(self, trainer):
+        d = Path(self.dirpath) if self.dirpath else trainer.log_dir / "checkpoints"
+        name = self.filename or f"epoch={trainer.current_epoch}-step={trainer.global_step}"
+        return d / f"{name}.ckpt"
+
+    def _save(self, trainer, module):
+        if trainer.global_rank != 0:
+            return
+        path = self._path(trainer)
+        trainer.save_checkpoint(path)
+        if self.filename is None:
+            self._saved.append(path)
+            while self.save_top_k is not None and 0 <= self.save_top_k < len(self._saved):
+                old = self._saved.pop(0)  # monitor="epoch", mode="max": newest wins
+                if old.exists():
+                    old.unlink()
+
+    def on_train_batch_end(self, trainer, module):
+        if self.train_time_interval is not None:
+            if time.monotonic() - self._last_time >= self.train_time_interval.total_seconds():
+                self._last_time = time.monotonic()
+                self._save(trainer, module)
+
+    def on_train_epoch_end(self, trainer, module):
+        if self.train_time_interval is None:
+            self._save(trainer, module)
+
+
+class CombinedLoader:
+    """dict of loaders, mode "max_size_cycle": epoch length = the longest loader, shorter ones cycle."""
+
+    def __init__(self, loaders):
+        self.loaders = loaders
+
+    def __len__(self):
+        return max(len(l) for l in self.loaders.values())
+
+    def __iter__(self):
+        n = len(self)
+        its = {k: (iter(l) if len(l) == n else itertools.cycle(l)) for k, l in self.loaders.items()}
+        for _ in range(n):
+            yield {k: next(it) for k, it in its.items()}
+
+
+def _to_device(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device, non_blocking=True)
+    if isinstance(x, dict):
+        return {k: _to_device(v, device) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_device(v, device) for v in x)
+    return x
+
+
+class Trainer:
+    def __init__(self, max_epochs=1, max_steps=-1, callbacks=None, log_every_n_steps=50, gpus=None,
+                 accelerator=None, devices=None, default_root_dir="lightning_logs", flush_every=100,
+                 enable_checkpointing=True, limit_train_batches=None):
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.callbacks = list(callbacks or [])
+        self.log_every_n_steps = log_every_n_steps
+        self.default_root_dir = Path(default_root_dir)
+        self.flush_every = flush_every
+        self.enable_checkpointing = enable_checkpointing
+        self.limit_train_batches = limit_train_batches
+        self.global_step = 0
+        self.current_epoch = 0
+        self.logger = None
+        self.optimizers, self.lr_schedulers = [], []
+        self.world_size, self.global_rank, self.local_rank = dist_utils.env_world()
+        self.log_dir = None
+        self._metric_rows = []
+        self.module = None
+
+    # ---- checkpoints ------------------------------------------------------------------------------
+    def save_checkpoint(self, path):
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        ckpt = {
+            "epoch": self.current_epoch,
+            "global_step": self.global_step,
+            "pytorch-lightning_version": "1.9.5+d3f-hip",
+            "state_dict": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
+            "optimizer_states": [o.state_dict() for o in self.optimizers],
+            "lr_schedulers": [s.state_dict() for s in self.lr_schedulers],
+            "hyper_parameters": dict(self.module.hparams),
+        }
+        tmp = path.with_suffix(".tmp")
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)
+
+    def _restore(self, ckpt_path):
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        self.module.load_state_dict(ckpt["state_dict"], strict=False)
+        for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+            o.load_state_dict(sd)
+        for s, sd in zip(self.lr_schedulers, ckpt.get("lr_schedulers", [])):
+            s.load_state_dict(sd)
+        self.current_epoch = int(ckpt.get("epoch", 0)) + 1  # resume after the saved epoch
+        self.global_step = int(ckpt.get("global_step", 0))
+
+    # ---- logging ------------------------------------------------------------------------------------
+    def _new_version_dir(self):
+        self.default_root_dir.mkdir(parents=True, exist_ok=True)
+        n = 0
+        while (self.default_root_dir / f"version_{n}").exists():
+            n += 1
+        d = self.default_root_dir / f"version_{n}"
+        if self.global_rank == 0:
+            d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def _flush_metrics(self):
+        if not self._metric_rows or self.global_rank != 0:
+            self._metric_rows = []
+            return
+        lines = []
+        for step, row in self._metric_rows:
+            vals = {k: (float(v) if not isinstance(v, (int, float)) else v) for k, v in row.items()}
+            lines.append(f"{step}," + ";".join(f"{k}={v:.6g}" for k, v in sorted(vals.items())))
+        with open(self.log_dir / "metrics.csv", "a") as f:
+            f.write("\n".join(lines) + "\n")
+        self._metric_rows = []
+
+    # ---- fit ----------------------------------------------------------------------------------------
+    def fit(self, model, ckpt_path=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("training needs an MI355X (HIP device); there is no CPU path")
+        self.module = model
+        dist_utils.init_process_group()
+        torch.cuda.set_device(self.local_rank)
+        device = torch.device("cuda", self.local_rank)
+        model.to(device)
+        model.train()
+        model.__dict__["trainer"] = self
+        self.log_dir = self._new_version_dir()
+
+        conf = model.configure_optimizers()
+        if isinstance(conf, tuple) and len(conf) == 2:
+            self.optimizers, self.lr_schedulers = list(conf[0]), list(conf[1])
+        elif isinstance(conf, (list, tuple)):
+            self.optimizers, self.lr_schedulers = list(conf), []
+        else:
+            self.optimizers, self.lr_schedulers = [conf], []
+        callbacks = list(self.callbacks)
+        if hasattr(model, "configure_callbacks"):
+            callbacks += list(model.configure_callbacks())
+        if self.enable_checkpointing and not any(isinstance(c, ModelCheckpoint) for c in callbacks):
+            callbacks.append(ModelCheckpoint())  # Lightning's default: one checkpoint per epoch
+        if ckpt_path is not None:
+            self._restore(ckpt_path)
+        for opt in self.optimizers:
+            mod = getattr(opt, "module", None)
+            if mod is not None:
+                dist_utils.DataParallel(mod, opt)
+        takes_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
+        opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
+
+        loaders = model.train_dataloader()
+        loader = CombinedLoader(loaders) if isinstance(loaders, dict) else loaders
+        for cb in callbacks:
+            cb.on_fit_start(self, model)
+        done = False
+        while self.current_epoch < self.max_epochs and not done:
+            for batch_idx, batch in enumerate(loader):
+                if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
+                    break
+                batch = _to_device(batch, device)
+                for oi, opt in enumerate(self.optimizers):
+                    if len(self.optimizers) > 1:  # toggle_optimizer
+                        for oj, ps in enumerate(opt_params):
+                            for p in ps:
+                                p.requires_grad_(oj == oi)
+                    opt.zero_grad(set_to_none=True)
+                    loss = model.training_step(batch, batch_idx, oi) if takes_idx else model.training_step(batch, batch_idx)
+                    loss.backward()
+                    opt.step()
+                    self.global_step += 1
+                if len(self.optimizers) > 1:
+                    for ps in opt_params:
+                        for p in ps:
+                            p.requires_grad_(True)
+                for cb in callbacks:
+                    cb.on_train_batch_end(self, model)
+                if self.global_step % max(self.log_every_n_steps, 1) == 0:
+                    self._metric_rows.append((self.global_step, dict(model._logged)))
+                if len(self._metric_rows) >= self.flush_every:
+                    self._flush_metrics()
+                if 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            for s in self.lr_schedulers:
+                s.step()
+            for cb in callbacks:
+                cb.on_train_epoch_end(self, model)
+            self._flush_metrics()
+            self.current_epoch += 1
+        torch.cuda.synchronize()
+        return self

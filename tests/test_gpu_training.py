@@ -1,0 +1,202 @@
+"""GPU: the training-step orchestration rows of SURVEY.md section 8 (a4, a5, a9, a10) -- the two
+LitModules, EMA, predict_fake, the trainer loop with checkpoints and the CLI -- against the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from util import max_rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+HP_DENOISER = dict(batch_size=4, learning_rate=0.02, max_epochs=2, cosine_scheduler_max_epoch=2, num_workers=0,
+                   encoder_name="resnet34", noise_exponential_sampling_lambda=5, mean=[128, 128, 128],
+                   std=[128, 128, 128], synthetic=True, image_size=64, augment=False, synthetic_length=8)
+HP_FAKE = dict(mode="denoise", batch_size=2, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=1,
+               cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
+               noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
+               std_b=[0.5] * 3, synthetic=True, image_size=64, synthetic_length=4, ema_beta=0.9999,
+               ema_update_every=1)
+
+
+def _device_draws(seed, shape):
+    """replay the device RNG stream of blend_random_amount_of_noise_with_each_sample"""
+    torch.manual_seed(seed)
+    noise = torch.randn(shape, device="cuda")
+    y = torch.rand(size=(shape[0], 1, 1, 1), device="cuda")
+    return noise.cpu(), y.reshape(-1).cpu()
+
+
+def _oracle_r(y, lam):
+    c = 1 / np.exp(lam)
+    return 1 / lam * torch.log(1 / (y * (1 - c) + c))
+
+
+def test_train_denoiser_step_matches_oracle():
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    torch.manual_seed(0)
+    lit = LitModule(**HP_DENOISER).cuda().train()
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    ref.load_state_dict({k: v.cpu() for k, v in lit.model.state_dict().items()})
+    ref64 = copy.deepcopy(ref).double()
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    x = oracle.synthetic_face_crops(4, 64, seed=21)
+    noise, y = _device_draws(123, x.shape)
+    torch.manual_seed(123)
+    loss = lit.training_step({"image": x.cuda(), "index": None}, 0)
+    noisy = oracle.step_oracle.blend_with_given_noise(x, noise, _oracle_r(y, 5))
+    l32 = crit(ref(noisy), x)
+    l64 = crit(ref64(noisy.double()), x.double())
+    assert abs(loss.item() - l64.item()) < max(4 * abs(l32.item() - l64.item()), 5e-6)
+    (opt,), (sched,) = lit.configure_optimizers()
+    before = lit.model.flat_params.clone()
+    loss.backward()
+    opt.step()
+    delta = (lit.model.flat_params - before).abs()
+    assert 0.019 < delta.max().item() <= 0.0201  # Adam's first step moves every element by ~lr
+    assert float(lit._logged["loss"]) == pytest.approx(loss.item())
+
+
+@pytest.mark.parametrize("mode", ["denoise", "swap"])
+def test_train_deep_fake_steps(mode):
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    torch.manual_seed(1)
+    lit = LitModule(**dict(HP_FAKE, mode=mode)).cuda().train()
+    assert (lit.ema_model_a is not None) == (mode == "swap")
+    keys = list(lit.state_dict().keys())
+    assert "model_a.encoder.conv1.weight" in keys and "model_b.segmentation_head.0.bias" in keys
+    if mode == "swap":
+        assert "ema_model_a.ema_model.encoder.conv1.weight" in keys and "ema_model_b.step" in keys
+        assert not any(k.startswith("ema_model_a.online_model") for k in keys)
+    opts, scheds = lit.configure_optimizers()
+    xa = oracle.synthetic_face_crops(2, 64, seed=31).cuda()
+    xb = oracle.synthetic_face_crops(2, 64, seed=32).cuda()
+    batch = {"a": {"image": xa, "index": None}, "b": {"image": xb, "index": None}}
+    # oracle replica of net a for the first optimiser step
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    ref.load_state_dict({k: v.cpu() for k, v in lit.model_a.state_dict().items()})
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    losses = []
+    for oi, opt in enumerate(opts):
+        opt.zero_grad(set_to_none=True)
+        if oi == 0 and mode == "denoise":
+            noise, y = _device_draws(77, xa.shape)
+            torch.manual_seed(77)
+        loss = lit.training_step(batch, 0, oi)
+        if oi == 0 and mode == "denoise":
+            noisy = oracle.step_oracle.blend_with_given_noise(xa.cpu(), noise, _oracle_r(y, 3))
+            l_ref = crit(ref(noisy), xa.cpu())
+            assert abs(loss.item() - l_ref.item()) < 2e-5
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    if mode == "swap":
+        # first update() copies online -> EMA (step <= update_after_step), and the teacher saw train-mode BN
+        assert lit.ema_model_b._host_step == 1 and lit.ema_model_a._host_step == 1
+        assert "swap_difference/a" in lit._logged and "loss_swap/train_b" in lit._logged
+    else:
+        assert "loss_denoise/train_a" in lit._logged
+
+
+def test_ema_matches_oracle():
+    import oracle
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd.optim import EMA
+    torch.manual_seed(2)
+    net = Unet("resnet34", None, 3, 3, None).cuda().prepare()
+    ref = oracle.Unet("resnet34", None, 3, 3, None)
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    ema = EMA(net, beta=0.9999, update_every=1, update_after_step=2)
+    ema_ref = oracle.EMA(ref, beta=0.9999, update_every=1, update_after_step=2)
+    g = torch.Generator().manual_seed(3)
+    for step in range(6):
+        d = torch.randn(net.flat_params.numel(), generator=g) * 0.01
+        with torch.no_grad():
+            net.flat_params.add_(d.cuda())
+            off = 0
+            for p in ref.parameters():
+                p.add_(d[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            for bn_h, bn_r in zip([m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)],
+                                  [m for m in ref.modules() if isinstance(m, torch.nn.BatchNorm2d)]):
+                bn_h.running_mean.add_(0.01 * (step + 1))
+                bn_r.running_mean.add_(0.01 * (step + 1))
+        ema.update()
+        ema_ref.update()
+        assert abs(ema.get_current_decay() - ema_ref.get_current_decay()) < 1e-12
+        sd, sd_ref = ema.ema_model.state_dict(), ema_ref.ema_model.state_dict()
+        for k in ("encoder.conv1.weight", "decoder.blocks.2.conv1.0.weight", "encoder.layer2.0.bn1.running_mean",
+                  "segmentation_head.0.bias"):
+            assert max_rel(sd[k], sd_ref[k]) < 2e-6, (step, k)
+    assert ema.initted.item() and ema.step.item() == 6
+
+
+def test_predict_fake_matches_oracle():
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    torch.manual_seed(4)
+    lit = LitModule(**HP_FAKE).cuda().eval()
+    ref = oracle.Unet("resnet34", None, 3, 3, None).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in lit.model_a.state_dict().items()})
+    rng = np.random.default_rng(0)
+    frame_bgr = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    out = lit.predict_fake(frame_bgr, "a")
+    assert out.shape == frame_bgr.shape and out.dtype == np.uint8
+    mean, std = torch.tensor([0.5] * 3), torch.tensor([0.5] * 3)
+    rgb = torch.from_numpy(np.ascontiguousarray(frame_bgr[:, :, ::-1])).float().permute(2, 0, 1)
+    x = ((rgb - mean.reshape(3, 1, 1) * 255) / (std.reshape(3, 1, 1) * 255)).unsqueeze(0)
+    with torch.no_grad():
+        y = ref(x)
+    want = oracle.tensor_to_uint8_denormalised(y, mean, std).numpy()[:, :, ::-1]
+    diff = np.abs(out.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01  # .int() truncation flips on float-noise ties only
+
+
+def test_trainer_fit_checkpoint_resume(tmp_path):
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    from denoising_diffusion_deep_fake_amd.trainer import Trainer
+    hp = dict(HP_DENOISER, default_root_dir=str(tmp_path))
+    torch.manual_seed(5)
+    lit = LitModule(**hp)
+    tr = Trainer(max_epochs=2, log_every_n_steps=1, default_root_dir=tmp_path).fit(lit)
+    assert tr.global_step == 4 and tr.current_epoch == 2  # 8 synthetic images / bs 4 = 2 steps per epoch
+    ckpts = sorted((tr.log_dir / "checkpoints").glob("*.ckpt"))
+    assert ckpts, "default ModelCheckpoint writes one file per epoch"
+    ck = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
+    assert set(ck) >= {"state_dict", "hyper_parameters", "optimizer_states", "lr_schedulers", "epoch", "global_step"}
+    assert "model.encoder.conv1.weight" in ck["state_dict"]
+    assert (tr.log_dir / "metrics.csv").read_text().count("loss=") == 4
+    # cosine schedule stepped once per epoch: lr(2 of T_max=2) = 0
+    assert tr.optimizers[0].param_groups[0]["lr"] == pytest.approx(0.0, abs=1e-9)
+    again = LitModule.load_from_checkpoint(ckpts[-1]).cuda().eval()
+    lit.eval()
+    x = torch.randn(1, 3, 64, 64).cuda()
+    with torch.no_grad():
+        torch.testing.assert_close(again(x), lit(x))
+    tr2 = Trainer(max_epochs=3, default_root_dir=tmp_path).fit(LitModule.load_from_checkpoint(ckpts[-1]), ckpt_path=ckpts[-1])
+    assert tr2.current_epoch == 3 and tr2.global_step == 6 and tr2.optimizers[0]._step == 6
+
+
+def test_cli_smoke(tmp_path):
+    from click.testing import CliRunner
+    from denoising_diffusion_deep_fake_amd.main import cli
+    cfg = tmp_path / "denoise.yml"
+    cfg.write_text(yaml.safe_dump(dict(HP_DENOISER, default_root_dir=str(tmp_path / "logs"))))
+    r = CliRunner().invoke(cli, ["denoise", "--config", str(cfg), "--max_steps", "2"])
+    assert r.exit_code == 0, r.output + str(r.exception)
+    cfg2 = tmp_path / "fake.yml"
+    cfg2.write_text(yaml.safe_dump(dict(HP_FAKE, default_root_dir=str(tmp_path / "logs2"))))
+    r = CliRunner().invoke(cli, ["train", "new", "--config_path", str(cfg2), "--max_steps", "2"])
+    assert r.exit_code == 0, r.output + str(r.exception)
+    last = next((tmp_path / "logs2").glob("version_*/checkpoints/last.ckpt"))
+    swap = tmp_path / "swap.yml"
+    swap.write_text(yaml.safe_dump(dict(mode="swap", max_epochs=1, ema_beta=0.9999, ema_update_every=1,
+                                        noise_exponential_sampling_lambda=8)))
+    r = CliRunner().invoke(cli, ["train", "modify", "--config_path", str(swap), "--checkpoint_path", str(last),
+                                 "--max_steps", "2"])
+    assert r.exit_code == 0, r.output + str(r.exception)
