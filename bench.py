@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the contraction kernels with HIP events in the timed region")

@@ -22,15 +22,26 @@ namespace d3f {
 
 constexpr int KP = 32;  // pixels per k-chunk
 
+// store one 16-byte global vector (4 f32 or 8 bf16) as f32 into LDS
+template <typename T> __device__ __forceinline__ void lds_store_as_f32(float* dst, const uint4& v);
+template <> __device__ __forceinline__ void lds_store_as_f32<float>(float* dst, const uint4& v) {
+  *reinterpret_cast<uint4*>(dst) = v;
+}
+template <> __device__ __forceinline__ void lds_store_as_f32<bf16_t>(float* dst, const uint4& v) {
+  *reinterpret_cast<uint4*>(dst) = make_uint4(v.x << 16, v.x & 0xffff0000u, v.y << 16, v.y & 0xffff0000u);
+  *reinterpret_cast<uint4*>(dst + 4) = make_uint4(v.z << 16, v.z & 0xffff0000u, v.w << 16, v.w & 0xffff0000u);
+}
+
+// T = activation type in memory (f32 or bf16).  The contraction itself runs on the f32 MFMA for both:
+// bf16 operands are widened when they are staged into LDS (exact), accumulation is f32.
 template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  static_assert(sizeof(T) == 4, "f32 only (bf16 wgrad: later round)");
+  constexpr int VE = Elem<T>::VE;
   constexpr int TM = BMW / WGM, TN = BNW / WGN, FM = TM / 32, FN = TN / 32;
-  constexpr int LY = BMW + 4, LX = BNW + 4;  // LDS row strides (floats), 16-B aligned rows
-  constexpr int VY = BMW / 4, VX = BNW / 4;  // 16-byte vectors per row
-  constexpr int NVY = KP * VY / 256, NVX = KP * VX / 256;
+  constexpr int LY = BMW + 4, LX = BNW + 4;    // LDS row strides (floats), 16-B aligned rows
+  constexpr int VY = BMW / VE, VX = BNW / VE;  // 16-byte global vectors per row
+  constexpr int NVY = (KP * VY + 255) / 256, NVX = (KP * VX + 255) / 256;
   static_assert(WGM * WGN * KSPLIT == 4, "4 waves");
-  static_assert(NVY >= 1 && NVX >= 1, "tile too small for 256 loader threads");
   constexpr int RED = (KSPLIT > 1) ? KSPLIT * 32 * 32 : 1;
   constexpr int LDS_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -57,12 +68,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(p.src0, p.src0_bytes);
   const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
 
-  // loader roles
-  const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*(256/VY)
+  // loader roles: vector id = tid + i*256 -> (row, vector column)
+  const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*YRS
   const int xcv = tid % VX, xrow0 = tid / VX;
   constexpr int YRS = 256 / VY, XRS = 256 / VX;
-  const int yco = co0 + ycv * 4;
-  const int xci = ci0 + xcv * 4;
+  static_assert(256 % VY == 0 && 256 % VX == 0, "vector columns must divide the workgroup");
+  const int yco = co0 + ycv * VE;
+  const int xci = ci0 + xcv * VE;
   const bool yvalid_c = yco < p.Cout;
   const bool xvalid_c = xci < Cin;
   const bool from0 = ci0 < p.C0;  // block-uniform: plan keeps ci tiles inside one source
@@ -91,23 +103,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int pix0 = ch * KP;
 #pragma unroll
     for (int i = 0; i < NVY; ++i) {
-      const int m = pix0 + yrow0 + i * YRS;
-      const bool ok = yvalid_c && m < p.M;
-      ry[i] = buf_load16(rdy, ok ? (unsigned)(m * p.Cout + yco) * 4u : BUF_OOB);
+      const int row = yrow0 + i * YRS;
+      const int m = pix0 + row;
+      const bool ok = yvalid_c && row < KP && m < p.M;
+      ry[i] = buf_load16(rdy, ok ? (unsigned)(m * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB);
     }
     unsigned off[NVX];
 #pragma unroll
     for (int i = 0; i < NVX; ++i) {
-      const int m = pix0 + xrow0 + i * XRS;
+      const int row = xrow0 + i * XRS;
+      const int m = pix0 + row;
       const int b = m / HoWo;
       const int r = m - b * HoWo;
       const int oy = r / p.Wo;
       const int ox = r - oy * p.Wo;
       const int iy = oy * p.stride - p.pad + kh;
       const int ix = ox * p.stride - p.pad + kw;
-      const bool ok = xvalid_c && m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+      const bool ok = xvalid_c && row < KP && m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
       const int pix = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
-      off[i] = ok ? (unsigned)(pix * Cs + xcl) * 4u : BUF_OOB;
+      off[i] = ok ? (unsigned)(pix * Cs + xcl) * (unsigned)sizeof(T) : BUF_OOB;
     }
     if (from0) {
 #pragma unroll
@@ -123,10 +137,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   for (int ch = chunk_begin; ch < chunk_end; ++ch) {
 #pragma unroll
     for (int i = 0; i < NVY; ++i)
-      *reinterpret_cast<uint4*>(&Ys[(yrow0 + i * YRS) * LY + ycv * 4]) = ry[i];
+      if (yrow0 + i * YRS < KP) lds_store_as_f32<T>(&Ys[(yrow0 + i * YRS) * LY + ycv * VE], ry[i]);
 #pragma unroll
     for (int i = 0; i < NVX; ++i)
-      *reinterpret_cast<uint4*>(&Xs[(xrow0 + i * XRS) * LX + xcv * 4]) = rx[i];
+      if (xrow0 + i * XRS < KP) lds_store_as_f32<T>(&Xs[(xrow0 + i * XRS) * LX + xcv * VE], rx[i]);
     __syncthreads();
     if (ch + 1 < chunk_end) load_chunk(ch + 1);
 #pragma unroll
@@ -220,23 +234,25 @@ static WTile pick_wtile(const WgradParams& p) {
   return {32, 32};
 }
 
-int wgrad_patch_variant(const WgradParams& p);
+int wgrad_patch_variant(const WgradParams& p, int dtype);
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy);
-int wgrad_patch_launch(const WgradParams& p, int variant, hipStream_t stream);
+int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t stream);
 
 int wgrad_plan(WgradParams& p, int dtype) {
-  D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
-  D3F_CHECK((p.C0 % 4) == 0 && (p.C1 % 4) == 0 && (p.Cout % 4) == 0,
-            "wgrad: channels (%d,%d,%d) must be multiples of 4", p.C0, p.C1, p.Cout);
+  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "wgrad: bad dtype %d", dtype);
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  const long es = dtype == D3F_F32 ? 4 : 2;
+  D3F_CHECK((p.C0 % ve) == 0 && (p.C1 % ve) == 0 && (p.Cout % ve) == 0,
+            "wgrad: channels (%d,%d,%d) must be multiples of %d", p.C0, p.C1, p.Cout, ve);
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.C1 == 0 || (p.C0 % t.bn) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t.bn);
-  const long bdy = (long)p.M * p.Cout * 4, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * 4,
-             b1 = (long)p.B * p.Hv * p.Wv * p.C1 * 4;
+  const long bdy = (long)p.M * p.Cout * es, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es,
+             b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
   D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
   p.dy_bytes = (unsigned)bdy; p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1;
-  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p);
+  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
     int gx, gy;
     wgrad_patch_grid(p, p.patch, &gx, &gy);
@@ -263,27 +279,32 @@ size_t wgrad_partial_floats(const WgradParams& p) {
   return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
 }
 
+template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream) {
+  const dim3 block(256);
+  if (bm == 128)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1>), grid, block, 0, stream, p);
+  else if (bm == 64)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4>), grid, block, 0, stream, p);
+}
+
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
-  D3F_CHECK(dtype == D3F_F32, "wgrad: only f32 is implemented (dtype %d)", dtype);
   if (p.M == 0) return 0;
   if (p.patch) {
     const bool prof = prof_enabled();
     if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
-    const int rc = wgrad_patch_launch(p, p.patch, stream);
+    const int rc = wgrad_patch_launch(p, p.patch, dtype, stream);
     if (prof) prof_end(stream);
     return rc;
   }
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
-  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits), block(256);
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits);
   const bool prof = prof_enabled();
   if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
-  if (t.bm == 128)
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 128, 128, 2, 2, 1>), grid, block, 0, stream, p);
-  else if (t.bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 2, 2, 1>), grid, block, 0, stream, p);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32, 32, 1, 1, 4>), grid, block, 0, stream, p);
+  if (dtype == D3F_F32) wgrad_launch_t<float>(p, t.bm, grid, stream);
+  else wgrad_launch_t<bf16_t>(p, t.bm, grid, stream);
   if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());
   return 0;

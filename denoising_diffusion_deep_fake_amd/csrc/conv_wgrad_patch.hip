@@ -32,8 +32,19 @@ template <> __device__ __forceinline__ void pmma<16>(f32x4& c, float a, float b)
 
 // MT: MFMA tile edge (32: 32x32x2, 16: 16x16x4); CO_T = MT output channels per workgroup slice;
 // CI_T input channels per slice; KS x KS taps, stride S; TW tile width.
-template <int MT, int CI_T, int KS, int S, int TW>
+template <typename T> __device__ __forceinline__ void patch_store_f32(float* dst, const uint4& v);
+template <> __device__ __forceinline__ void patch_store_f32<float>(float* dst, const uint4& v) {
+  *reinterpret_cast<uint4*>(dst) = v;
+}
+template <> __device__ __forceinline__ void patch_store_f32<bf16_t>(float* dst, const uint4& v) {
+  *reinterpret_cast<uint4*>(dst) = make_uint4(v.x << 16, v.x & 0xffff0000u, v.y << 16, v.y & 0xffff0000u);
+  *reinterpret_cast<uint4*>(dst + 4) = make_uint4(v.z << 16, v.z & 0xffff0000u, v.w << 16, v.w & 0xffff0000u);
+}
+
+// T: activation type in memory; bf16 operands are widened to f32 when staged (f32 MFMA, f32 accumulate)
+template <typename T, int MT, int CI_T, int KS, int S, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams p) {
+  constexpr int VE = Elem<T>::VE;
   constexpr int CO_T = MT;
   constexpr int PH = (PT_TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int KSTEP = (MT == 32) ? 2 : 4;            // pixels per MFMA
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + PT_TH - 1) / PT_TH;
   const int ntiles = p.B * tiles_y * tiles_x;
-  constexpr int VX = CI_T / 4, VY = CO_T / 4;  // 16-byte vectors per pixel row
+  constexpr int VX = CI_T / VE, VY = CO_T / VE;  // 16-byte global vectors per pixel row
 
   // staging: every load of a tile is issued into registers first (no load -> wait -> store chains),
   // and the NEXT tile's loads are issued before the MFMA sweep of the current one.
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
       const int iy = oy0 * S - p.pad + py, ix = ox0 * S - p.pad + px;
       const bool ok = v < PH * PW * VX && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
       const int gp = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
-      rxv[i] = buf_load16(rx, ok ? (unsigned)(gp * Cs + cl0 + cv * 4) * 4u : BUF_OOB);
+      rxv[i] = buf_load16(rx, ok ? (unsigned)(gp * Cs + cl0 + cv * VE) * (unsigned)sizeof(T) : BUF_OOB);
     }
 #pragma unroll
     for (int i = 0; i < NVY; ++i) {
@@ -114,9 +125,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
       const int pix = v / VY, cv = v - pix * VY;
       const int y = pix / TW, x = pix - y * TW;
       const int oy = oy0 + y, ox = ox0 + x;
-      const int co = co0 + cv * 4;
+      const int co = co0 + cv * VE;
       const bool ok = v < PT_TH * TW * VY && oy < p.Ho && ox < p.Wo && co < p.Cout;
-      ryv[i] = buf_load16(rdy, ok ? (unsigned)(((b * p.Ho + oy) * p.Wo + ox) * p.Cout + co) * 4u : BUF_OOB);
+      ryv[i] = buf_load16(rdy, ok ? (unsigned)(((b * p.Ho + oy) * p.Wo + ox) * p.Cout + co) * (unsigned)sizeof(T) : BUF_OOB);
     }
   };
   auto store_tile = [&]() {
@@ -124,13 +135,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
     for (int i = 0; i < NVX; ++i) {
       const int v = tid + i * 256;
       const int pix = v / VX, cv = v - pix * VX;
-      if (v < PH * PW * VX) *reinterpret_cast<uint4*>(&Xs[pix * LXS + cv * 4]) = rxv[i];
+      if (v < PH * PW * VX) patch_store_f32<T>(&Xs[pix * LXS + cv * VE], rxv[i]);
     }
 #pragma unroll
     for (int i = 0; i < NVY; ++i) {
       const int v = tid + i * 256;
       const int pix = v / VY, cv = v - pix * VY;
-      if (v < PT_TH * TW * VY) *reinterpret_cast<uint4*>(&Ys[pix * LYS + cv * 4]) = ryv[i];
+      if (v < PT_TH * TW * VY) patch_store_f32<T>(&Ys[pix * LYS + cv * VE], ryv[i]);
     }
   };
 
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 
 // variants: 1: 3x3 s1, <=16 out, 32-channel slices (decoder 4 conv1)   2: 3x3 s1, <=16 out, 16-channel slices
 //           3: 3x3 s1, 32-out slices, 32-channel slices (decoder 3)     4: 7x7 s2 stem, 4 (3+pad) channels
-int wgrad_patch_variant(const WgradParams& p) {
+int wgrad_patch_variant(const WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   if (p.KH != p.KW) return 0;
   if (p.KH == 3 && p.stride == 1 && p.pad == 1) {
@@ -201,8 +212,9 @@ int wgrad_patch_variant(const WgradParams& p) {
     if (p.Cout <= 16 && cin == 16) return 2;
     if (p.Cout == 32 && cin % 32 == 0 && cin <= 128 && (p.C1 == 0 || p.C0 % 32 == 0)) return 3;
   }
-  if (p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 4 && p.C1 == 0 && p.Cout % 32 == 0 && p.Cout <= 64)
-    return 4;
+  if (dtype == D3F_F32 && p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 4 && p.C1 == 0 &&
+      p.Cout % 32 == 0 && p.Cout <= 64)
+    return 4;  // f32 only: bf16 pads the stem input to 8 channels
   return 0;
 }
 
@@ -219,17 +231,29 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   *gy = slices;
 }
 
-int wgrad_patch_launch(const WgradParams& p, int variant, hipStream_t stream) {
+template <typename T> static int patch_launch_t(const WgradParams& p, int variant, dim3 grid, hipStream_t stream) {
+  const dim3 block(256);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((conv_wgrad_patch_kernel<T, 16, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_patch_kernel<T, 16, 16, 3, 1, 16>), grid, block, 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((conv_wgrad_patch_kernel<T, 32, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
+    default: return set_error(-1, "wgrad patch: bad variant %d", variant);
+  }
+  return 0;
+}
+
+int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t stream) {
   int gx, gy;
   wgrad_patch_grid(p, variant, &gx, &gy);
   D3F_CHECK(p.splits == gx, "wgrad patch: params were not planned (splits %d vs %d)", p.splits, gx);
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
-  switch (variant) {
-    case 1: hipLaunchKernelGGL((conv_wgrad_patch_kernel<16, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((conv_wgrad_patch_kernel<16, 16, 3, 1, 16>), grid, block, 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((conv_wgrad_patch_kernel<32, 32, 3, 1, 16>), grid, block, 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((conv_wgrad_patch_kernel<32, 4, 7, 2, 16>), grid, block, 0, stream, p); break;
-    default: return set_error(-1, "wgrad patch: bad variant %d", variant);
+  if (variant == 4) {
+    D3F_CHECK(dtype == D3F_F32, "wgrad patch: the stem variant is f32 only");
+    hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
+  } else if (dtype == D3F_F32) {
+    if (int rc = patch_launch_t<float>(p, variant, grid, stream)) return rc;
+  } else {
+    if (int rc = patch_launch_t<bf16_t>(p, variant, grid, stream)) return rc;
   }
   D3F_HIP(hipGetLastError());
   return 0;

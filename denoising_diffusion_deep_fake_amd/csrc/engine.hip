@@ -177,8 +177,8 @@ int UnetEngine::plan_unit(Unit& u) {
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = f.M;
   g.flops = 2.0 * macs;
-  if (dtype == D3F_F32) {
-    if (int rc = wgrad_plan(g, dtype)) return rc;
+  if (int rc = wgrad_plan(g, dtype)) return rc;
+  {
     const size_t wb = wgrad_partial_floats(g) * sizeof(float);
     if (wb > wpart_bytes) wpart_bytes = wb;
   }
@@ -476,7 +476,6 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
 
 int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
                          int seg_begin, int seg_end, hipStream_t s) const {
-  D3F_CHECK(dtype == D3F_F32, "unet backward: only f32 is implemented (dtype %d)", dtype);
   char* ws = reinterpret_cast<char*>(ws_);
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };

@@ -1,0 +1,99 @@
+"""GPU, world_size 2 (both ranks on the one MI355X, gloo transport): the data-parallel integration --
+engine backward cut into buckets, each bucket's flat-gradient slice all-reduced as soon as it is
+final, FusedAdam joining and folding 1/world into the update.  RCCL needs one device per rank, so the
+8-GPU run is the driver's; what is proven here is that the hook fires per bucket in order, covers the
+whole flat gradient exactly once, and that the reduced gradient equals the sum of the ranks' gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.distributed import DataParallel, init_process_group
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    init_process_group("gloo")
+    torch.cuda.set_device(0)
+    torch.manual_seed(100 + rank)           # deliberately different init per rank: broadcast must fix it
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    opt = FusedAdam(net.parameters(), lr=0.01, betas=(0.5, 0.999), module=net)
+    calls = []
+    dp = DataParallel(net, opt)
+    inner = dp.reducer
+
+    def spy(seg, sl):
+        calls.append((seg, sl.data_ptr(), sl.numel()))
+        inner(seg, sl)
+
+    net.set_grad_sync(spy)
+    w0 = net.flat_params.clone()
+    gathered = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    same_init = all(torch.equal(g, gathered[0]) for g in gathered)
+
+    x = synthetic_face_crops(2, 64, seed=50 + rank, device="cuda")   # distinct shard per rank
+    # local gradient without the hook, for the expected sum
+    net.set_grad_sync(None)
+    pred = net(x)
+    _, g = ops.mse_ssim_loss(pred.detach(), x)
+    pred.backward(g)
+    local = net.flat_grads.clone()
+    expect = local.clone()
+    dist.all_reduce(expect)
+    for p in net.parameters():
+        p.grad = None
+    # restore BN statistics / counters do not matter for the gradient check; run the hooked pass
+    net.set_grad_sync(spy)
+    pred = net(x)
+    _, g = ops.mse_ssim_loss(pred.detach(), x)
+    pred.backward(g)
+    inner.wait()
+    reduced = net.flat_grads.clone()
+    err = ((reduced - expect).norm() / expect.norm()).item()
+    segs = [c[0] for c in calls]
+    covered = sum(c[2] for c in calls)
+    base = net.flat_grads.data_ptr()
+    back_to_front = all(calls[i][1] > calls[i + 1][1] for i in range(len(calls) - 1)) and calls[-1][1] == base
+    before = net.flat_params.clone()
+    opt.step()
+    step = (net.flat_params - before).abs().max().item()
+    after = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(after, net.flat_params.clone())
+    in_sync = all(torch.equal(a, after[0]) for a in after)
+    ret[rank] = dict(same_init=same_init, err=err, segs=segs, covered=covered, n=net.flat_grads.numel(),
+                     back_to_front=back_to_front, step=step, in_sync=in_sync, scale=opt.grad_scale)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        o = ret[r]
+        assert o["same_init"], "rank 0's parameters must be broadcast"
+        assert o["segs"] == [0, 1, 2, 3] and o["covered"] == o["n"] == 24_436_659 and o["back_to_front"]
+        # identical inputs, one pass with the hook and one without: only the summation order inside
+        # gloo differs from the explicit all_reduce
+        assert o["err"] < 1e-6, o["err"]
+        assert o["scale"] == 0.5
+        assert 0.009 < o["step"] <= 0.0101   # Adam's first step, averaged gradient
+        assert o["in_sync"], "replicas must stay bit-identical after the step"
