@@ -33,6 +33,10 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the contraction kernels with HIP events in the timed region")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50"],
+                    help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
+                         "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
+                         "batch of 64 (BASELINE config 4)")
     return ap.parse_args()
 
 
@@ -84,8 +88,61 @@ def cpu_baseline(size, batch, steps):
                       f"torch.set_num_threads({cores})"}
 
 
+def extra_workload(args):
+    """secondary workloads of BASELINE.json (not the headline metric): one JSON line each."""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    if args.workload == "deepfake":
+        from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+        bs = 8
+        lit = LitModule(mode="denoise", batch_size=bs, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=50,
+                        cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
+                        noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
+                        std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype).to(dev).train()
+        opts, _ = lit.configure_optimizers()
+        batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i, device=dev), "index": None}
+                 for i, k in enumerate("ab")}
+
+        def step(i):
+            for oi, opt in enumerate(opts):
+                opt.zero_grad(set_to_none=True)
+                loss = lit.training_step(batch, i, oi)
+                loss.backward()
+                opt.step()
+            return loss
+        images_per_step, name = 2 * bs, f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain"
+    else:
+        from denoising_diffusion_deep_fake_amd import Unet
+        net = Unet("resnet34", None, 3, 3, None, compute_dtype=args.dtype).to(dev).eval()
+        x = synthetic_face_crops(64, args.size, seed=3, device=dev)
+
+        @torch.no_grad()
+        def step(i):
+            y = x
+            for _ in range(50):
+                y = net(y).clamp_(-1.0, 1.0)  # keep the fed-back "image" in range (random-init weights)
+            return y.mean()
+        images_per_step, name = 64, "50 eval-mode forwards (BatchNorm folded) of a batch of 64, output fed back"
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": name, "dtype": args.dtype, "image_size": args.size, "steps": args.steps,
+           "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "images_per_sec": round(images_per_step * args.steps / dt, 2), "last": float(out.item())}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload != "denoiser":
+        return extra_workload(args)
     from denoising_diffusion_deep_fake_amd import _lib
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
     from denoising_diffusion_deep_fake_amd.distributed import DataParallel, init_process_group

@@ -1,0 +1,97 @@
+"""GPU: the optional bf16 activation mode (compute_dtype="bf16": bf16 activations / packed weights,
+f32 accumulation, f32 master weights, f32 statistics and weight gradients).
+
+Stated tolerance.  Single operators, inputs pre-rounded to bf16: products are exact in f32, so the only
+difference to an f32 evaluation is the final rounding of the output to bf16 (2^-9 relative per element):
+rel-L2 <= 4e-3 for forward / data gradient (measured 1.7e-3), <= 1e-5 for the f32 weight gradient
+(measured 1e-7).  Whole network: this BatchNorm-heavy net amplifies rounding ~100x (f32: 7e-6 forward
+error from 6e-8 rounding); with 2^-8 activation rounding the measured distance to the f32 CPU oracle is
+6.7e-2 / 7.5e-2 rel-L2 forward (B=4 64x64 / B=8 128x128), loss within 3e-4, flat-gradient cosine 0.80 /
+0.88.  Gates: forward rel-L2 <= 0.15, |loss - oracle| <= 2e-3, gradient cosine >= 0.6 -- bf16 is a
+throughput mode, the f32 path is the parity-graded one (tests/test_gpu_unet.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import rel_l2, to_nchw, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (2, 16, 16, 64, 0, 64, 3, 1, 1, False),
+    (2, 16, 16, 64, 64, 32, 3, 1, 1, True),
+    (2, 16, 16, 32, 0, 16, 3, 1, 1, True),
+    (2, 16, 16, 16, 0, 16, 3, 1, 1, False),
+    (1, 8, 8, 256, 0, 256, 3, 1, 1, False),
+    (2, 16, 16, 64, 0, 128, 3, 2, 1, False),
+    (2, 16, 16, 64, 0, 128, 1, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_bf16(case):
+    from denoising_diffusion_deep_fake_amd import ops
+    B, H, W, C0, C1, Co, k, s, pd, up = case
+    g = torch.Generator().manual_seed(0)
+    h0, w0 = (H // 2, W // 2) if up else (H, W)
+    x0 = torch.randn(B, C0, h0, w0, generator=g).bfloat16().float()
+    x1 = torch.randn(B, C1, H, W, generator=g).bfloat16().float() if C1 else None
+    w = (torch.randn(Co, C0 + C1, k, k, generator=g) / ((C0 + C1) * k * k) ** 0.5).bfloat16().float()
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up else x0
+    if C1:
+        xin = torch.cat([xin, x1], 1)
+    xin = xin.requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xin, wr, None, s, pd)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    d = ops.make_desc(B, H, W, C0, C1, Co, k, s, pd, up)
+    s0 = to_nhwc(x0).bfloat16().cuda()
+    s1 = to_nhwc(x1).bfloat16().cuda() if C1 else None
+    wf, wd = ops.pack_weights(d, w.cuda(), dtype=ops.BF16)
+    y, stats, tiles = ops.conv_forward(d, s0, s1, wf, dtype=ops.BF16, splitk=True)
+    assert rel_l2(to_nchw(y.float().cpu()), y_ref) < 4e-3
+    st = stats.view(tiles, (Co + 15) // 16 * 16, 2).double().sum(0).cpu()
+    # statistics come from the f32 accumulators, not from the rounded outputs
+    assert rel_l2(st[:Co, 1], (y_ref.detach().double() ** 2).sum((0, 2, 3))) < 1e-5
+    dyh = to_nhwc(dy, (Co + 7) // 8 * 8).bfloat16().cuda()
+    dx0, dx1 = ops.conv_backward_data(d, dyh, wd, dtype=ops.BF16, splitk=True)
+    assert rel_l2(to_nchw(dx0.float().cpu()), xin.grad[:, :C0]) < 4e-3
+    if C1:
+        assert rel_l2(to_nchw(dx1.float().cpu()), xin.grad[:, C0:]) < 4e-3
+    dw = ops.conv_backward_weight(d, dyh, s0, s1, dtype=ops.BF16)
+    assert rel_l2(dw.cpu(), wr.grad) < 1e-5
+
+
+def test_unet_bf16_training_step():
+    import oracle
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    torch.manual_seed(1)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16")
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().train()
+    B, S = 4, 64
+    x = oracle.synthetic_face_crops(B, S, seed=11)
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(x.shape, generator=g)
+    r = torch.rand(B, generator=g) * 0.5 + 0.05
+    noisy = oracle.step_oracle.blend_with_given_noise(x, noise, r)
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    pr = ref(noisy)
+    lr = crit(pr, x)
+    lr.backward()
+    pred = net(noisy.cuda())
+    lossv, gp = ops.mse_ssim_loss(pred.detach(), x.cuda())
+    pred.backward(gp)
+    assert pred.dtype == torch.float32            # boundary tensors stay f32
+    assert rel_l2(pred, pr) < 0.15
+    assert abs(lossv[0].item() - lr.item()) < 2e-3
+    g32 = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    cos = F.cosine_similarity(net.flat_grads.cpu().double(), g32.double(), dim=0).item()
+    assert cos > 0.6, cos
+    assert torch.isfinite(net.flat_grads).all()
+    net.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert rel_l2(net(noisy.cuda()), ref(noisy)) < 0.05
