@@ -98,6 +98,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int total_chunks = (p.M + KP - 1) / KP;
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
+  // incremental pixel decode (see load_chunk): valid when a 32-pixel step is a whole number of image
+  // rows (32 % Wo == 0, and rows-per-step <= Ho) or stays within at most one row wrap (Wo % 32 == 0)
+  const bool wo_ge = (p.Wo % KP) == 0;
+  const int rows_per_chunk = wo_ge ? 0 : KP / (p.Wo > 0 ? p.Wo : 1);
+  const bool incr = wo_ge || ((KP % p.Wo) == 0 && rows_per_chunk <= p.Ho);
+  int xb[NVX], xoy[NVX], xox[NVX];
+#pragma unroll
+  for (int i = 0; i < NVX; ++i) {
+    const int m = chunk_begin * KP + xrow0 + i * XRS;
+    const int b = m / HoWo;
+    const int r = m - b * HoWo;
+    xb[i] = b;
+    xoy[i] = r / p.Wo;
+    xox[i] = r - xoy[i] * p.Wo;
+  }
   uint4 ry[NVY], rx[NVX];
   auto load_chunk = [&](int ch) {
     const int pix0 = ch * KP;
@@ -113,10 +128,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < NVX; ++i) {
       const int row = xrow0 + i * XRS;
       const int m = pix0 + row;
-      const int b = m / HoWo;
-      const int r = m - b * HoWo;
-      const int oy = r / p.Wo;
-      const int ox = r - oy * p.Wo;
+      int b, oy, ox;
+      if (incr) {
+        // (b, oy, ox) of this thread's row, advanced by exactly KP = 32 pixels per chunk: two integer
+        // divisions per row per chunk would cost ~100 VALU, and VALU time adds to the f32 MFMA time
+        b = xb[i]; oy = xoy[i]; ox = xox[i];
+        if (wo_ge) {            // Wo is a multiple of 32: at most one row wrap
+          int nx = ox + KP;
+          const int w = nx >= p.Wo ? 1 : 0;
+          nx -= w ? p.Wo : 0;
+          int ny = oy + w;
+          const int h = ny >= p.Ho ? 1 : 0;
+          ny = h ? 0 : ny;
+          xox[i] = nx; xoy[i] = ny; xb[i] = b + h;
+        } else {                // Wo divides 32: the column stays, rows advance by 32 / Wo
+          int ny = oy + rows_per_chunk;
+          const int h = ny >= p.Ho ? 1 : 0;
+          ny -= h ? p.Ho : 0;
+          xoy[i] = ny; xb[i] = b + h;
+        }
+      } else {
+        b = m / HoWo;
+        const int r = m - b * HoWo;
+        oy = r / p.Wo;
+        ox = r - oy * p.Wo;
+      }
       const int iy = oy * p.stride - p.pad + kh;
       const int ix = ox * p.stride - p.pad + kw;
       const bool ok = xvalid_c && row < KP && m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;

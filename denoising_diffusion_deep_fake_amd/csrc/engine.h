@@ -69,6 +69,7 @@ struct BwdOp {
 
 class UnetEngine {
  public:
+  ~UnetEngine();
   int build(const char* encoder, int in_channels, int classes, int B, int H, int W, int dtype);
 
   int pack_weights(const float* params, void* ws, hipStream_t s) const;
@@ -107,6 +108,12 @@ class UnetEngine {
   std::vector<bool> grad_init;    // plan-time: has a writer been emitted yet
   std::vector<BwdOp> bwd_ops;
   std::vector<int> fwd_order_;    // unit ids in execution order, -1 = max-pool
+  // backward concurrency: weight gradients run on a side stream next to the data-gradient / BN chain
+  mutable hipStream_t side_ = nullptr;
+  static constexpr int NDY = 4;  // dY buffers: how far the side stream may lag behind the main chain
+  mutable hipEvent_t ev_dy_[NDY] = {}, ev_wg_[NDY] = {}, ev_join_ = nullptr;
+  mutable bool wg_pending_[NDY] = {};
+  size_t dyn_off[NDY] = {};
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;
   size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dy_off = 0, dz_off = 0, dfull_off = 0,

@@ -7,6 +7,7 @@
 // smp-compatible state_dict keys.
 #include "engine.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace d3f {
@@ -351,6 +352,8 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   stats_off = alloc(stats_bytes);
   bnpart_off = alloc(bnpart_bytes);
   dy_off = alloc(dy_bytes);
+  dyn_off[0] = dy_off;  // ring of dY buffers: the side-stream wgrad of unit i reads one while later units write the others
+  for (int i = 1; i < NDY; ++i) dyn_off[i] = alloc(dy_bytes);
   dz_off = alloc(dz_bytes);
   dfull_off = alloc(dfull_bytes);
   wpart_off = alloc(wpart_bytes);
@@ -474,13 +477,41 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
   return 0;
 }
 
+UnetEngine::~UnetEngine() {
+  for (int i = 0; i < NDY; ++i) {
+    if (ev_dy_[i]) (void)hipEventDestroy(ev_dy_[i]);
+    if (ev_wg_[i]) (void)hipEventDestroy(ev_wg_[i]);
+  }
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (side_) (void)hipStreamDestroy(side_);
+}
+
+// Backward of segments [seg_begin, seg_end).  Per unit: BN backward (writes dY) -> {weight gradient,
+// data gradient}.  The two gradients are independent, and the following unit's BN-backward kernels are
+// HBM-bound while the weight gradient is MFMA-bound, so the weight gradient (+ its slab reduce) runs on
+// a side stream: main records "dY ready", side waits for it; dY is double-buffered and main waits for the
+// side-stream reader of a buffer before overwriting it; the side stream is joined before returning, so
+// after the call every gradient of the segment is final on the caller's stream.
 int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
                          int seg_begin, int seg_end, hipStream_t s) const {
   char* ws = reinterpret_cast<char*>(ws_);
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
-  char* dy = ws + dy_off;
+  static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob
+  if (!serial && side_ == nullptr) {
+    D3F_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    for (int i = 0; i < NDY; ++i) {
+      D3F_HIP(hipEventCreateWithFlags(&ev_dy_[i], hipEventDisableTiming));
+      D3F_HIP(hipEventCreateWithFlags(&ev_wg_[i], hipEventDisableTiming));
+    }
+    D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  }
+  hipStream_t ws_stream = serial ? s : side_;
+  char* dybuf[NDY];
+  for (int i = 0; i < NDY; ++i) dybuf[i] = ws + dyn_off[i];
   float* wpart = reinterpret_cast<float*>(ws + wpart_off);
+  int flip = 0;
+  bool side_used = false;
   for (const BwdOp& op : bwd_ops) {
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
     if (op.kind == BW_SUM2X2) {
@@ -496,6 +527,13 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
     const Unit& u = units[op.unit];
     const long rows = (long)B * u.Ho * u.Wo;
+    const int cur = flip;
+    flip = (flip + 1) % NDY;
+    char* dy = dybuf[cur];
+    if (!serial && wg_pending_[cur]) {  // the wgrad that read this buffer two units ago must be done
+      D3F_HIP(hipStreamWaitEvent(s, ev_wg_[cur], 0));
+      wg_pending_[cur] = false;
+    }
     if (op.kind == BW_HEAD) {
       if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s)) return rc;
       if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
@@ -519,17 +557,26 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
                                        u.Cout, s))
         return rc;
     }
-    // weight gradient
+    // weight gradient (side stream)
+    if (!serial) {
+      D3F_HIP(hipEventRecord(ev_dy_[cur], s));
+      D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[cur], 0));
+    }
     WgradParams g = u.wg;
     g.dy = dy;
     g.src0 = T(u.in0);
     g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
     g.partial = wpart;
-    if (int rc = wgrad_launch(g, dtype, s)) return rc;
+    if (int rc = wgrad_launch(g, dtype, ws_stream)) return rc;
     if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW,
-                                     grads + u.w_off, 0, s))
+                                     grads + u.w_off, 0, ws_stream))
       return rc;
-    // data gradient
+    if (!serial) {
+      D3F_HIP(hipEventRecord(ev_wg_[cur], side_));
+      wg_pending_[cur] = true;
+      side_used = true;
+    }
+    // data gradient (main stream)
     if (u.need_dgrad) {
       ConvParams d = u.dgrad;
       d.src0 = dy;
@@ -546,6 +593,11 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(d, dtype, s)) return rc;
     }
+  }
+  if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream
+    D3F_HIP(hipEventRecord(ev_join_, side_));
+    D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+    for (int i = 0; i < NDY; ++i) wg_pending_[i] = false;
   }
   return 0;
 }

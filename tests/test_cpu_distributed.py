@@ -10,6 +10,21 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _spawn_with_deadline(fn, args, nprocs, seconds=150):
+    """mp.spawn, but a stuck rank fails the test instead of hanging it (and never outlives it)."""
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    import time
+    t0 = time.monotonic()
+    try:
+        while not ctx.join(timeout=5):
+            if time.monotonic() - t0 > seconds:
+                raise TimeoutError(f"ranks still running after {seconds}s")
+    finally:
+        for proc in ctx.processes:
+            if proc.is_alive():
+                proc.terminate()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -41,7 +56,7 @@ def test_bucket_allreduce_world2():
     ranges = [(700, 1000), (400, 700), (150, 400), (0, 150)]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ranges, ret), nprocs=world, join=True)
+    _spawn_with_deadline(_worker, (world, _free_port(), ranges, ret), world, seconds=90)
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] == [0, 1, 2, 3, 4] and ret[1][1] == [5, 6, 7, 8, 9]
 

@@ -14,6 +14,21 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _spawn_with_deadline(fn, args, nprocs, seconds=150):
+    """mp.spawn, but a stuck rank fails the test instead of hanging it (and never outlives it)."""
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    import time
+    t0 = time.monotonic()
+    try:
+        while not ctx.join(timeout=5):
+            if time.monotonic() - t0 > seconds:
+                raise TimeoutError(f"ranks still running after {seconds}s")
+    finally:
+        for proc in ctx.processes:
+            if proc.is_alive():
+                proc.terminate()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -86,7 +101,7 @@ def test_data_parallel_two_ranks_one_gpu():
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    _spawn_with_deadline(_worker, (world, _free_port(), ret), world)
     for r in range(world):
         o = ret[r]
         assert o["same_init"], "rank 0's parameters must be broadcast"
