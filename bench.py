@@ -240,8 +240,14 @@ def main():
         ach = fl[0] / ms[0] / 1e9
         for k in (1, 2):
             per[k]["concurrent"] = True
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.dtype == "f32" and args.size == 256 and args.batch == 16:
+            # PMC counters cannot be read from inside this process: per-launch HBM bytes of the same launches,
+            # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic,
                            "kernel": "conv_igemm_kernel (forward launches; its data-gradient launches overlap "
                                      "the weight-gradient kernel on a second stream)",
                            "launches": int(n[0]), "avg_launch_us": round(1e3 * ms[0] / n[0], 2),

@@ -327,6 +327,105 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }(std::make_integer_sequence<int, NPIECE>{});
   };
 
+  if constexpr (FAST && DB) {
+    // ---- lean main loop for plain gathers ---------------------------------------------------------
+    // Microbenchmark (profiles/README.md): next to 16 MFMAs per k-tile, ~32 dependent SALU cost 30 % and
+    // loads that get only one compute phase to land cost 20 %.  Here the scalar state is incremental --
+    // with one NHWC source the byte offset of a k-tile advances by 128 per tile and jumps once per filter
+    // row -- and two register sets keep the loads of tiles t+2 and t+3 in flight while tile t computes.
+    const unsigned step_bytes = BKE * (unsigned)sizeof(T);
+    const int cpt = Cin / BKE;                                        // k-tiles per tap
+    const unsigned rowjump = (unsigned)((p.Wv - p.KW) * p.C0) * (unsigned)sizeof(T);
+    unsigned ld_delta, ld_bit, ld_w;                                  // state of the LOAD stream (runs ahead)
+    int ld_cleft, ld_kwleft;
+    {
+      const int tap0 = kt_begin / cpt, c0 = kt_begin - tap0 * cpt;
+      const int kh0 = tap0 / p.KW, kw0 = tap0 - kh0 * p.KW;
+      ld_delta = (unsigned)((kh0 * p.Wv + kw0) * p.C0 + c0 * BKE) * (unsigned)sizeof(T);
+      ld_bit = (unsigned)tap0;
+      ld_cleft = cpt - c0;
+      ld_kwleft = p.KW - kw0;
+      ld_w = (unsigned)kt_begin * step_bytes;
+    }
+    uint4 ra2[NVA], rb2[NVB];  // second register set
+    auto issue_piece = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB], auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < NVA) {
+        A[q] = buf_load16(r0, ((vmask[q] >> ld_bit) & 1u) ? rowoff[q] + ld_delta : BUF_OOB);
+      } else {
+        Bv[q - NVA] = buf_load16(rw, woff[q - NVA] + ld_w);  // an OOB row keeps bit 31 set
+      }
+    };
+    auto advance = [&]() {  // branch-free, ~10 SALU
+      ld_w += step_bytes;
+      ld_delta += step_bytes;
+      const int tapwrap = (--ld_cleft == 0) ? 1 : 0;
+      ld_cleft = tapwrap ? cpt : ld_cleft;
+      ld_bit += (unsigned)tapwrap;
+      ld_kwleft -= tapwrap;
+      const int rowwrap = (ld_kwleft == 0) ? 1 : 0;
+      ld_kwleft = rowwrap ? p.KW : ld_kwleft;
+      ld_delta += rowwrap ? rowjump : 0u;
+    };
+    auto issue_all = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
+      [&]<int... Q>(std::integer_sequence<int, Q...>) {
+        (issue_piece(A, Bv, std::integral_constant<int, Q>{}), ...);
+      }(std::make_integer_sequence<int, NVA + NVB>{});
+      advance();
+    };
+    auto stage_set = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB]) {
+      uint32_t* As = lds + buf * STAGE;
+      uint32_t* Bs = As + BM * LDS_ROW;
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) *reinterpret_cast<uint4*>(&As[(rbase + 32 * i) * LDS_ROW + chunk * 4]) = A[i];
+#pragma unroll
+      for (int j = 0; j < NVB; ++j) *reinterpret_cast<uint4*>(&Bs[(rbase + 32 * j) * LDS_ROW + chunk * 4]) = Bv[j];
+    };
+    constexpr int NMF = NS * FM * FN * M_::NINST;
+    constexpr int NPC = NVA + NVB;
+    constexpr int EV = (NMF / NPC) > 0 ? (NMF / NPC) : 1;
+    // compute tile from LDS `buf`; the pieces of the next load go behind individual MFMAs
+    auto compute_issue = [&](int buf, uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
+      compute(buf, [&](int n) {
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+          ((n == Q * EV ? (issue_piece(A, Bv, std::integral_constant<int, Q>{}), 0) : 0), ...);
+        }(std::make_integer_sequence<int, NPC>{});
+      });
+      [&]<int... Q>(std::integer_sequence<int, Q...>) {
+        ((Q * EV >= NMF ? (issue_piece(A, Bv, std::integral_constant<int, Q>{}), 0) : 0), ...);
+      }(std::make_integer_sequence<int, NPC>{});
+      advance();
+    };
+    const int n = kt_end - kt_begin;
+    // prologue: tiles 0, 1 in flight; tile 0 staged; tile 2 in flight in the freed set
+    issue_all(ra, rb);
+    if (n > 1) issue_all(ra2, rb2);
+    stage_set(0, ra, rb);
+    if (n > 2) issue_all(ra, rb);
+    __syncthreads();
+    int t = 0;
+    // steady state, unrolled by two so that LDS stage and register set are static:
+    //   iteration t: stage tile t+1 (set (t+1)&1), re-issue that set with tile t+3, compute tile t
+    for (; t + 4 < n; t += 2) {
+      stage_set(1, ra2, rb2);        // tile t+1
+      compute_issue(0, ra2, rb2);    // tile t; loads of tile t+3 -> set 1
+      __syncthreads();
+      stage_set(0, ra, rb);          // tile t+2
+      compute_issue(1, ra, rb);      // tile t+1; loads of tile t+4 -> set 0
+      __syncthreads();
+    }
+    for (; t < n; ++t) {             // tail (at most 4 tiles): same schedule with bounds checks
+      const int cur = t & 1;
+      if (t + 1 < n) {
+        if (cur == 0) stage_set(1, ra2, rb2); else stage_set(0, ra, rb);
+      }
+      if (t + 3 < n) {
+        if (cur == 0) issue_all(ra2, rb2); else issue_all(ra, rb);
+      }
+      compute(cur, no_hook);
+      __syncthreads();
+    }
+  } else
   if constexpr (!DB) {
     // single LDS stage: stage -> barrier -> (next tile's loads behind the MFMAs) -> barrier
     load_tile(kt_begin);

@@ -2,7 +2,6 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -10,11 +9,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 4 = 4 x ds_write_b128 per k-tile, 8 = ~64 dummy VALU per k-tile, 16 = two independent accumulators,
 // 32 = ~32 dependent SALU per k-tile, 64 = 4 buffer-style global loads per k-tile (L2 resident, consumed
 // by the next k-tile's LDS writes), 128 = 12 cheap VALU per k-tile (the FAST address path)
-template <int MODE, bool RANDOM>
+template <int MODE>
 __global__ __launch_bounds__(256) void bench(float* out, int nk, const float* in) {
   __shared__ __attribute__((aligned(16))) unsigned lds[2 * 128 * 36];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 2 * 128 * 36; i += 256) lds[i] = RANDOM ? __float_as_uint(in[(i * 7 + blockIdx.x) & 4095]) : (unsigned)i;
+  for (int i = tid; i < 2 * 128 * 36; i += 256) lds[i] = (unsigned)i;
   __syncthreads();
   f32x16 acc = {0}, acc2 = {0};
   float a0 = in[tid], b0 = in[tid + 256];
@@ -78,11 +77,11 @@ __global__ __launch_bounds__(256) void bench(float* out, int nk, const float* in
   out[blockIdx.x * 256 + tid] = s + (float)(va + vb) + (float)(sa + sb) + __uint_as_float(ld[0].x ^ ld[1].y ^ ld[2].z ^ ld[3].w);
 }
 
-template <int MODE, bool RANDOM = false> void run(const char* name, int blocks, int nk, float* out, float* in) {
+template <int MODE> void run(const char* name, int blocks, int nk, float* out, float* in) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((bench<MODE, RANDOM>), dim3(blocks), dim3(256), 0, 0, out, nk, in);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(bench<MODE>, dim3(blocks), dim3(256), 0, 0, out, nk, in);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((bench<MODE, RANDOM>), dim3(blocks), dim3(256), 0, 0, out, nk, in);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(bench<MODE>, dim3(blocks), dim3(256), 0, 0, out, nk, in);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 100.0;  // per launch
@@ -92,19 +91,7 @@ template <int MODE, bool RANDOM = false> void run(const char* name, int blocks, 
 
 int main() {
   float *out, *in; CK(hipMalloc(&out, 4096 * 256 * 4)); CK(hipMalloc(&in, 16384 * 16 + 4096)); CK(hipMemset(in, 0, 16384 * 16 + 4096));
-  {
-    std::vector<float> h(16384 * 4 + 1024);
-    unsigned st = 12345;
-    for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
-    CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  }
   for (int blocks : {512}) {
-    const int nk2 = 36 * 512 / blocks * 4;
-    run<0, true>("RANDOM data: mfma only", blocks, nk2, out, in);
-    run<1, true>("RANDOM data: + lds reads", blocks, nk2, out, in);
-    run<1 | 2 | 4, true>("RANDOM data: reads+barrier+writes", blocks, nk2, out, in);
-    run<1 | 2 | 4 | 128, true>("RANDOM data: + 12 cheap VALU", blocks, nk2, out, in);
-    run<1 | 2 | 4 | 32 | 64 | 128, true>("RANDOM data: + SALU + VALU + loads", blocks, nk2, out, in);
     const int nk = 36 * 512 / blocks * 4;  // long enough to amortise launch
     run<0>("mfma only (1 acc chain)", blocks, nk, out, in);
     run<16>("mfma only (2 acc chains)", blocks, nk, out, in);
