@@ -153,6 +153,8 @@ def main():
     world, rank, local = init_process_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("D3F_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (gloo)
+        local = int(os.environ["D3F_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)  # identical init on every rank (and broadcast from rank 0 anyway)

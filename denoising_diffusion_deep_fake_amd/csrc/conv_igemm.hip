@@ -749,7 +749,6 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(p.CoutPad >= p.Cout, "conv: CoutPad");
   D3F_CHECK(p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0, "conv: Cout=%d must be a multiple of 4 (vector epilogue)", p.Cout);
   D3F_CHECK(p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0, "conv: out_c0=%d must be a multiple of 4", p.out_c0);
-  D3F_CHECK(p.mode != CONV_HEAD_NCHW || !allow_splitk || true, "unreachable");
   D3F_CHECK(p.C1 == 0 || (p.C0 % bke) == 0, "conv: C0=%d must be a multiple of %d when a second source is concatenated", p.C0, bke);
   const long es = dtype == D3F_F32 ? 4 : 2;
   const long b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es, b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;

@@ -100,7 +100,6 @@ class UnetEngine {
                int Cout, int k, int stride, int pad, bool bn, bool bias, bool relu, bool apply,
                int segment);
   int plan_unit(Unit& u);
-  void bind(ConvParams& p, const Unit& u, char* ws) const;
 
   std::vector<TensorD> tensors;   // activations
   std::vector<TensorD> gtensors;  // activation gradients
@@ -117,7 +116,7 @@ class UnetEngine {
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;
   size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dy_off = 0, dz_off = 0, dfull_off = 0,
-         wpart_off = 0, dyh_off = 0, bsum_off = 0, splitk_off = 0;
+         wpart_off = 0, bsum_off = 0, splitk_off = 0;
   size_t stats_bytes = 0, bnpart_bytes = 0, dy_bytes = 0, dz_bytes = 0, dfull_bytes = 0, wpart_bytes = 0, splitk_bytes = 0;
 };
 

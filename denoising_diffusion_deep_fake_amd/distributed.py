@@ -28,7 +28,8 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # D3F_DIST_BACKEND: test hook (two ranks sharing one GPU need gloo; RCCL wants a device per rank)
+            backend = os.environ.get("D3F_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local)

@@ -17,7 +17,6 @@ engine (csrc/engine.hip), which enqueues the hand-written gfx950 kernels on the 
 stream.  There is no eager / CPU fallback: tensors must live on a HIP device.
 """
 import ctypes as C
-import math
 
 import torch
 import torch.nn as nn
