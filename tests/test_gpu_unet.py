@@ -196,3 +196,35 @@ def test_resnet18_runs():
     assert y.shape == x.shape and torch.isfinite(y).all()
     y.mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_authors_resolution_448():
+    """The reference's own configs train on 448x448 crops (denoise_config.yml:13): extents 224/112/56/28/14
+    are not powers of two, so this covers the wgrad loader's division fallback, ragged patch tiles and odd
+    tile counts.  B=1 keeps the CPU float64 oracle affordable."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd import ops
+    ref, net = _pair(seed=3)
+    x = oracle.synthetic_face_crops(1, 448, seed=9)
+    ref64 = copy.deepcopy(ref).double().train()
+    ref.train()
+    net.train()
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    p32 = ref(x)
+    crit(p32, x).backward()
+    p64 = ref64(x.double())
+    l64 = crit(p64, x.double())
+    l64.backward()
+    pred = net(x.cuda())
+    lossv, gpred = ops.mse_ssim_loss(pred.detach(), x.cuda())
+    pred.backward(gpred)
+    e_hip, e_cpu = rel_l2(pred, p64), rel_l2(p32, p64)
+    assert _within(e_hip, e_cpu, CAP_FWD, 2e-6), (e_hip, e_cpu)
+    assert abs(lossv[0].item() - l64.item()) < 1e-5
+    g64 = torch.cat([p.grad.reshape(-1) for p in ref64.parameters()])
+    g32 = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    e_hip, e_cpu = rel_l2(net.flat_grads, g64), rel_l2(g32, g64)
+    print("448x448 flat gradient rel-L2 vs float64: hip %.3e cpu-fp32 %.3e" % (e_hip, e_cpu))
+    assert _within(e_hip, e_cpu, CAP_GRAD_FLAT, 2e-5, NOISE_GRAD), (e_hip, e_cpu)
+    worst = max(rel_l2(p2.grad, p3.grad) for (_, p2), (_, p3) in zip(net.named_parameters(), ref64.named_parameters()))
+    assert worst < CAP_GRAD_TENSOR, worst
