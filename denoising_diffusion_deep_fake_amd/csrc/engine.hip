@@ -545,16 +545,21 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       float* invstd = coef_ptr(ws, u, 1);
       float* k = coef_ptr(ws, u, 4);
       float* bnpart = reinterpret_cast<float*>(ws + bnpart_off);
-      const void* amask = op.mask ? T(u.a) : nullptr;
+      // ReLU mask: layers without a residual recompute it from y (f32: bit-identical to a > 0, since the
+      // forward apply used the same y*scale + shift); residual layers and bf16 read the saved activation
+      const bool from_y = op.mask && dtype == D3F_F32 && u.res_tensor < 0 && u.res_unit < 0;
+      const void* amask = (op.mask && !from_y) ? T(u.a) : nullptr;
+      const float* msc = from_y ? coef_ptr(ws, u, 2) : nullptr;
+      const float* msf = from_y ? coef_ptr(ws, u, 3) : nullptr;
       if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
-                                        u.Cout, s))
+                                        u.Cout, s, msc, msf))
         return rc;
       if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
                                           grads + u.g_off, grads + u.b_off, 0, k, s))
         return rc;
       if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
                                        op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
-                                       u.Cout, s))
+                                       u.Cout, s, msc, msf))
         return rc;
     }
     // weight gradient (side stream)

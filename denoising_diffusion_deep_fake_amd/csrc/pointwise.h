@@ -23,7 +23,8 @@ int bn_apply_launch(int dtype, const void* y, const float* scale, const float* s
 // backward: dz = dA * (a > 0 if a given);  partial sums of dz and dz*xhat
 int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
                          const float* mean, const float* invstd, float* partial, int* nblocks,
-                         long rows, int C, hipStream_t stream);
+                         long rows, int C, hipStream_t stream, const float* mask_scale = nullptr,
+                         const float* mask_shift = nullptr);
 int bn_bwd_reduce_blocks(long rows, int C, int dtype);
 int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
@@ -31,7 +32,8 @@ int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
 // dy = k1*(dz - k2 - xhat*k3); optionally dz -> dres (+= if dres_acc)
 int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
                         const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
-                        long rows, int C, hipStream_t stream);
+                        long rows, int C, hipStream_t stream, const float* mask_scale = nullptr,
+                        const float* mask_shift = nullptr);
 
 // ---- pooling / resampling / layout (K6, K8 backward, boundary) ---------------------------
 int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,

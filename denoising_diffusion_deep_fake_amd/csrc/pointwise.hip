@@ -204,11 +204,13 @@ int bn_bwd_reduce_blocks(long rows, int C, int dtype) {
   return (int)b;
 }
 
+// ReLU mask: from the saved activation `a` (a > 0), or -- for layers without a residual, mask_scale !=
+// null -- recomputed from y with the forward's own arithmetic (y*scale + shift > 0), which saves reading `a`.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
-    long rows, int C) {
+    long rows, int C, const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
   constexpr int N = V16<T>::N;
   __shared__ float red[256 * N * 2];
   const int VC = C / N;        // vectors per row (power of two, <= 256)
@@ -218,11 +220,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   const long rbeg = (long)blockIdx.x * rows_per_block;
   long rend = rbeg + rows_per_block;
   if (rend > rows) rend = rows;
-  float mu[N], is[N], s1[N], s2[N];
+  float mu[N], is[N], s1[N], s2[N], msc[N], msf[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     mu[k] = mean[cv * N + k];
     is[k] = invstd[cv * N + k];
+    msc[k] = mask_scale ? mask_scale[cv * N + k] : 0.f;
+    msf[k] = mask_scale ? mask_shift[cv * N + k] : 0.f;
     s1[k] = 0.f;
     s2[k] = 0.f;
   }
@@ -231,7 +235,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float g[N], yy[N];
     V16<T>::load(dA + off, g);
     V16<T>::load(y + off, yy);
-    if (a != nullptr) {
+    if (mask_scale != nullptr) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
+    } else if (a != nullptr) {
       float aa[N];
       V16<T>::load(a + off, aa);
 #pragma unroll
@@ -261,7 +268,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 
 int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
                          const float* mean, const float* invstd, float* partial, int* nblocks,
-                         long rows, int C, hipStream_t stream) {
+                         long rows, int C, hipStream_t stream, const float* mask_scale,
+                         const float* mask_shift) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   const int vc = C / ve;
   D3F_CHECK(C % ve == 0 && vc >= 1 && vc <= 256 && (256 % vc) == 0,
@@ -270,10 +278,12 @@ int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y
   *nblocks = blocks;
   if (dtype == D3F_F32)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream,
-                       (const float*)dA, (const float*)a, (const float*)y, mean, invstd, partial, rows, C);
+                       (const float*)dA, (const float*)a, (const float*)y, mean, invstd, partial, rows, C,
+                       mask_scale, mask_shift);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
-                       (const bf16_t*)dA, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, partial, rows, C);
+                       (const bf16_t*)dA, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, partial, rows, C,
+                       mask_scale, mask_shift);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -315,14 +325,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-    T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C) {
+    T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C,
+    const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
   constexpr int N = V16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int c0 = (int)((i * N) % C);
     float g[N], yy[N], o[N];
     V16<T>::load(dA + i * N, g);
     V16<T>::load(y + i * N, yy);
-    if (a != nullptr) {
+    if (mask_scale != nullptr) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = (yy[k] * mask_scale[c0 + k] + mask_shift[c0 + k]) > 0.f ? g[k] : 0.f;
+    } else if (a != nullptr) {
       float aa[N];
       V16<T>::load(a + i * N, aa);
 #pragma unroll
@@ -349,7 +363,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
                         const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
-                        long rows, int C, hipStream_t stream) {
+                        long rows, int C, hipStream_t stream, const float* mask_scale,
+                        const float* mask_shift) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0, "bn_bwd_apply: C=%d", C);
   const long nvec = rows * C / ve;
@@ -358,11 +373,11 @@ int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y,
   if (dtype == D3F_F32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)dA,
                        (const float*)a, (const float*)y, mean, invstd, coef, (float*)dy, (float*)dres,
-                       dres_acc, nvec, C);
+                       dres_acc, nvec, C, mask_scale, mask_shift);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dA,
                        (const bf16_t*)a, (const bf16_t*)y, mean, invstd, coef, (bf16_t*)dy, (bf16_t*)dres,
-                       dres_acc, nvec, C);
+                       dres_acc, nvec, C, mask_scale, mask_shift);
   D3F_HIP(hipGetLastError());
   return 0;
 }
