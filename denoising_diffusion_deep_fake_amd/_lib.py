@@ -32,6 +32,7 @@ PROTOTYPES = {
     "d3f_version": (_i, []),
     "d3f_last_error": (C.c_char_p, []),
     "d3f_profile_enable": (_i, [_i]),
+    "d3f_profile_classes": (_i, [_i]),
     "d3f_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3f_unet_create": (_i, [C.c_char_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "d3f_unet_destroy": (_i, [_p]),

@@ -30,7 +30,8 @@ struct ProfRec {
 static std::vector<ProfRec> g_prof;  // pre-created event pairs
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
-bool prof_enabled() { return g_prof_on && g_prof_used < g_prof.size(); }
+static int g_prof_mask = 7;  // bit per class
+bool prof_enabled(int cls) { return g_prof_on && ((g_prof_mask >> cls) & 1) && g_prof_used < g_prof.size(); }
 void prof_begin(int cls, double flops, hipStream_t s) {
   ProfRec& r = g_prof[g_prof_used];
   r.cls = cls;
@@ -131,6 +132,11 @@ int d3f_profile_enable(int max_launches) {
   g_prof_on = true;
   return 0;
 }
+int d3f_profile_classes(int mask) {
+  g_prof_mask = mask & 7;
+  return 0;
+}
+
 int d3f_profile_collect(double ms[3], int64_t launches[3], double flops[3]) {
   D3F_CHECK(ms && launches && flops, "profile_collect: null argument");
   for (int k = 0; k < 3; ++k) { ms[k] = 0; launches[k] = 0; flops[k] = 0; }

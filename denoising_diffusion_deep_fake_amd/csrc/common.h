@@ -82,7 +82,7 @@ static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 // to report achieved FLOP/s of the contraction kernels against the MFMA roofline.
 // ---------------------------------------------------------------------------------------
 enum ProfClass : int { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_WGRAD = 2, PROF_NUM = 3 };
-bool prof_enabled();
+bool prof_enabled(int cls);
 void prof_begin(int cls, double flops, hipStream_t s);
 void prof_end(hipStream_t s);
 

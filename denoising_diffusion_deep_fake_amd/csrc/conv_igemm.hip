@@ -822,8 +822,9 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
     if (ablate[0] == 'w' || ablate[0] == 'b') q.w_bytes = 0;                    // weights
   }
   D3F_CHECK(q.splitk == 1 || q.stat_rows == cdiv(q.M, SK_ROWS), "conv: split-K params were not planned");
-  const bool prof = prof_enabled();
-  if (prof) prof_begin(q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD, q.flops, stream);
+  const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
+  const bool prof = prof_enabled(prof_cls);
+  if (prof) prof_begin(prof_cls, q.flops, stream);
   int rc = dtype == D3F_F32 ? launch_t<float>(q, smallc, stream) : launch_t<bf16_t>(q, smallc, stream);
   if (rc == 0 && q.splitk > 1) {
     const dim3 grid((unsigned)cdiv(q.M, SK_ROWS)), block(256);

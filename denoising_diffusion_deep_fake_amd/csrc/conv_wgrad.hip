@@ -328,7 +328,7 @@ template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, d
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (p.M == 0) return 0;
   if (p.patch) {
-    const bool prof = prof_enabled();
+    const bool prof = prof_enabled(PROF_WGRAD);
     if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
     const int rc = wgrad_patch_launch(p, p.patch, dtype, stream);
     if (prof) prof_end(stream);
@@ -337,7 +337,7 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits);
-  const bool prof = prof_enabled();
+  const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
   if (dtype == D3F_F32) wgrad_launch_t<float>(p, t.bm, grid, stream);
   else wgrad_launch_t<bf16_t>(p, t.bm, grid, stream);

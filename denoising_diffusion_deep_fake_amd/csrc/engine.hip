@@ -391,14 +391,39 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
 
 // ------------------------------------------------------------------------------------------
 int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) const {
-  char* ws = reinterpret_cast<char*>(ws_);
+  D3F_CHECK((int)units.size() <= PACK_MAX_LAYERS, "pack_weights: %d layers exceed the table", (int)units.size());
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  PackTable t;
+  t.n = 0;
+  uint32_t blocks = 0;
   for (const Unit& u : units) {
-    if (int rc = pack_weights_launch(dtype, params_ + u.w_off, u.Cout, u.CinReal, u.Cin(), u.KH, u.KW,
-                                     ws + u.wf_off, u.CoutPad, u.Kpad,
-                                     u.need_dgrad ? ws + u.wd_off : nullptr, u.CinRows, u.KpadD, s))
-      return rc;
+    PackEntry& e = t.e[t.n++];
+    const int CoutD = (int)round_up(u.Cout, ve);
+    const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
+    D3F_CHECK(u.Kpad >= u.KH * u.KW * u.Cin() && (!u.need_dgrad || u.KpadD >= u.KH * u.KW * CoutD),
+              "pack_weights: padded K too small");
+    D3F_CHECK(u.wf_off % 16 == 0 && u.wd_off % 16 == 0 && (u.wf_off >> 4) < 0xffffffffull &&
+                  (u.wd_off >> 4) < 0xffffffffull && nf + nd < 0x7fffffffl && u.Kpad < 65536 && u.KpadD < 65536,
+              "pack_weights: layer out of table range");
+    e.w_off = (uint32_t)u.w_off;
+    e.wf_off16 = (uint32_t)(u.wf_off >> 4);
+    e.wd_off16 = (uint32_t)(u.wd_off >> 4);
+    e.block0 = blocks;
+    e.Cout = (uint16_t)u.Cout; e.CinReal = (uint16_t)u.CinReal; e.Cin = (uint16_t)u.Cin();
+    e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
+    e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
+    e.has_d = u.need_dgrad ? 1 : 0;
+    const int taps = u.KH * u.KW;
+    D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
+    int CT = 32;
+    while (CT * taps > PACK_LDS_ROW) CT >>= 1;
+    const int crows = std::max(u.Cin(), u.need_dgrad ? u.CinRows : 0);
+    const int nrows = std::max(u.CoutPad, u.need_dgrad ? CoutD : 0);
+    e.CT = (uint16_t)CT;
+    e.ctiles = (uint16_t)((crows + CT - 1) / CT);
+    blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
   }
-  return 0;
+  return pack_all_launch(dtype, params_, ws_, t, (int)blocks, s);
 }
 
 static inline float* coef_ptr(char* ws, const Unit& u, int which) {

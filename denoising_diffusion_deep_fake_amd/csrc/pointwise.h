@@ -56,6 +56,23 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
                         void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
                         hipStream_t stream);
 
+// every layer of a network in one launch (engine): table passed by value as a kernel argument
+constexpr int PACK_MAX_LAYERS = 64;
+constexpr int PACK_NT = 32;        // filters per tile
+constexpr int PACK_LDS_ROW = 288;  // floats per filter in a tile: CT channels x taps  (32 x 9)
+struct PackEntry {
+  uint32_t w_off;               // floats into the flat parameter buffer
+  uint32_t wf_off16, wd_off16;  // 16-byte units into the workspace
+  uint32_t block0;              // first block of this layer; blocks are (filter tile, channel tile)
+  uint16_t Cout, CinReal, Cin, taps, CoutPad, Kpad, CinRows, CoutD, KpadD, has_d, CT, ctiles;
+};
+struct PackTable {
+  int n;
+  PackEntry e[PACK_MAX_LAYERS];
+};
+int pack_all_launch(int dtype, const float* params, void* ws, const PackTable& t, int blocks,
+                    hipStream_t stream);
+
 // ---- noise blend (K12), loss (K13), Adam (K14), EMA (K15) --------------------------------
 int noise_blend_launch(const float* x, const float* noise, const float* y_uniform, float lam,
                        float* out, float* r_out, int B, long per_image, hipStream_t stream);

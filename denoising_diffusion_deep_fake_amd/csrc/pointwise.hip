@@ -230,24 +230,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     s1[k] = 0.f;
     s2[k] = 0.f;
   }
-  for (long r = rbeg + r0; r < rend; r += RP) {
-    const long off = r * C + cv * N;
-    float g[N], yy[N];
-    V16<T>::load(dA + off, g);
-    V16<T>::load(y + off, yy);
-    if (mask_scale != nullptr) {
+  // U rows per trip: all loads of a trip are issued before any arithmetic (memory-level parallelism)
+  constexpr int U = 4;
+  const bool from_y = mask_scale != nullptr, from_a = !from_y && a != nullptr;
+  long r = rbeg + r0;
+  for (; r + (U - 1) * RP < rend; r += U * RP) {
+    float g[U][N], yy[U][N], aa[U][N];
 #pragma unroll
-      for (int k = 0; k < N; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
-    } else if (a != nullptr) {
-      float aa[N];
-      V16<T>::load(a + off, aa);
-#pragma unroll
-      for (int k = 0; k < N; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const long off = (r + u * RP) * C + cv * N;
+      V16<T>::load(dA + off, g[u]);
+      V16<T>::load(y + off, yy[u]);
+      if (from_a) V16<T>::load(a + off, aa[u]);
     }
 #pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float keep = from_y ? yy[u][k] * msc[k] + msf[k] : (from_a ? aa[u][k] : 1.f);
+        const float gz = keep > 0.f ? g[u][k] : 0.f;
+        s1[k] += gz;
+        s2[k] += gz * ((yy[u][k] - mu[k]) * is[k]);
+      }
+    }
+  }
+  for (; r < rend; r += RP) {
+    const long off = r * C + cv * N;
+    float g[N], yy[N], aa[N];
+    V16<T>::load(dA + off, g);
+    V16<T>::load(y + off, yy);
+    if (from_a) V16<T>::load(a + off, aa);
+#pragma unroll
     for (int k = 0; k < N; ++k) {
-      s1[k] += g[k];
-      s2[k] += g[k] * ((yy[k] - mu[k]) * is[k]);
+      const float keep = from_y ? yy[k] * msc[k] + msf[k] : (from_a ? aa[k] : 1.f);
+      const float gz = keep > 0.f ? g[k] : 0.f;
+      s1[k] += gz;
+      s2[k] += gz * ((yy[k] - mu[k]) * is[k]);
     }
   }
 #pragma unroll
@@ -663,6 +681,78 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
   else
     hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
                        CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// All layers of a network in one launch: the table travels as a kernel argument (no device-side state) and a
+// block looks its layer up by its first block index.  A block transposes one [32 filters][CT channels][taps]
+// tile through LDS: the torch layout [n][c][tap] is read in contiguous runs of CT*taps floats and both packed
+// layouts ([n][tap][c] and [c][flipped tap][n]) are written in contiguous runs; padding rows/columns of the
+// packed matrices are (re)written as zeros by the edge tiles, so the workspace needs no initialisation.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ params, char* __restrict__ ws,
+                                                       PackTable t) {
+  __shared__ float tile[PACK_NT * (PACK_LDS_ROW + 1)];
+  int l = 0;
+  while (l + 1 < t.n && blockIdx.x >= t.e[l + 1].block0) ++l;
+  const PackEntry e = t.e[l];
+  const float* __restrict__ w = params + e.w_off;
+  T* __restrict__ wf = reinterpret_cast<T*>(ws + (size_t)e.wf_off16 * 16);
+  T* __restrict__ wd = reinterpret_cast<T*>(ws + (size_t)e.wd_off16 * 16);
+  const int taps = e.taps, Cin = e.Cin, CinReal = e.CinReal, Cout = e.Cout, Kpad = e.Kpad, KpadD = e.KpadD,
+            CoutD = e.CoutD, CT = e.CT, CoutPad = e.CoutPad, CinRows = e.CinRows;
+  const int rel = (int)(blockIdx.x - e.block0);
+  const int nt = rel / e.ctiles, ct = rel % e.ctiles;
+  const int n0 = nt * PACK_NT, c0 = ct * CT;
+  const int run = CT * taps, stride = run + 1;  // LDS row: [c_l][tap]
+  // ---- load: contiguous runs of the torch layout, zero outside the real filter ----
+  for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
+    const int nl = i / run, r = i % run;
+    const int n = n0 + nl, c = c0 + r / taps;
+    float v = 0.f;
+    if (n < Cout && c < CinReal) v = w[((long)n * CinReal + c0) * taps + r];
+    tile[nl * stride + r] = v;
+  }
+  __syncthreads();
+  // ---- forward layout wf[n][tap*Cin + c] ----
+  for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
+    const int cl = i % CT, tap = (i / CT) % taps, nl = i / run;
+    const int n = n0 + nl, c = c0 + cl;
+    if (n < CoutPad && c < Cin) wf[(long)n * Kpad + tap * Cin + c] = from_f32<T>(tile[nl * stride + cl * taps + tap]);
+  }
+  if (ct == 0) {  // zero tail of each row: k in [taps*Cin, Kpad)
+    const int k0 = taps * Cin, tail = Kpad - k0;
+    for (int i = threadIdx.x; i < PACK_NT * tail; i += 256) {
+      const int n = n0 + i / tail;
+      if (n < CoutPad) wf[(long)n * Kpad + k0 + i % tail] = from_f32<T>(0.f);
+    }
+  }
+  // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
+  if (e.has_d) {
+    for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
+      const int nl = i % PACK_NT, tapf = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
+      const int n = n0 + nl, c = c0 + cl;
+      if (c < CinRows && n < CoutD)
+        wd[(long)c * KpadD + tapf * CoutD + n] = from_f32<T>(tile[nl * stride + cl * taps + (taps - 1 - tapf)]);
+    }
+    if (nt == 0) {
+      const int k0 = taps * CoutD, tail = KpadD - k0;
+      for (int i = threadIdx.x; i < CT * tail; i += 256) {
+        const int c = c0 + i / tail;
+        if (c < CinRows) wd[(long)c * KpadD + k0 + i % tail] = from_f32<T>(0.f);
+      }
+    }
+  }
+}
+
+int pack_all_launch(int dtype, const float* params, void* ws, const PackTable& t, int blocks,
+                    hipStream_t stream) {
+  if (t.n == 0 || blocks == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(pack_all_kernel<float>, dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
+  else
+    hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
   D3F_HIP(hipGetLastError());
   return 0;
 }

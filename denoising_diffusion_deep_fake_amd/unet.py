@@ -17,6 +17,7 @@ engine (csrc/engine.hip), which enqueues the hand-written gfx950 kernels on the 
 stream.  There is no eager / CPU fallback: tensors must live on a HIP device.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -101,6 +102,8 @@ class _Engine:
         self.shape = (B, H, W)
         self.dtype = dtype
         self.workspace = torch.empty(L.d3f_unet_workspace_bytes(self.h), dtype=torch.uint8, device=device)
+        if os.environ.get("D3F_POISON_WORKSPACE"):  # test hook: any read-before-write shows up as NaN
+            self.workspace.fill_(0xFF)
         self.packed_version = None
         self.fwd_flops = L.d3f_unet_forward_flops(self.h)
         self.bwd_flops = L.d3f_unet_backward_flops(self.h)

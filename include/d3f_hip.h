@@ -39,8 +39,11 @@ const char* d3f_last_error(void);
  * (class 0 = conv forward, 1 = conv data-gradient, 2 = conv weight-gradient) is bracketed by a pair
  * of HIP events on the launch stream.  collect() waits for them and returns, per class, the summed
  * kernel time (ms), the number of launches and their algorithmic FLOPs, then resets the buffer.
- * max_launches <= 0 disables.  collect() returns 1 if the buffer overflowed. */
+ * max_launches <= 0 disables.  collect() returns 1 if the buffer overflowed.
+ * d3f_profile_classes(mask) restricts the bracketing to the classes whose bit is set (default 7 = all):
+ * an event pair costs a few microseconds of stream time, so a timed run brackets only what it reports. */
 int d3f_profile_enable(int max_launches);
+int d3f_profile_classes(int mask);
 int d3f_profile_collect(double ms[3], int64_t launches[3], double flops[3]);
 
 /* ---------------------------------------------------------------------------------------

@@ -1,0 +1,38 @@
+import time, torch, sys, os
+sys.path.insert(0, os.getcwd())
+from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+from denoising_diffusion_deep_fake_amd.distributed import DataParallel
+from denoising_diffusion_deep_fake_amd import _lib
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+lit = LitModule(batch_size=16, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100, num_workers=0,
+                encoder_name="resnet34", noise_exponential_sampling_lambda=5, mean=[128]*3, std=[128]*3,
+                synthetic=True, image_size=256, augment=False, precision="f32").to(dev).train()
+(opt,), _ = lit.configure_optimizers()
+DataParallel(lit.model, opt)
+data = [synthetic_face_crops(16, 256, seed=1234 + i, device=dev) for i in range(4)]
+T = {"zero": 0.0, "train_step": 0.0, "backward": 0.0, "opt": 0.0}
+def step(i, rec):
+    t0 = time.perf_counter(); opt.zero_grad(set_to_none=True)
+    t1 = time.perf_counter(); loss = lit.training_step({"image": data[i % 4], "index": None}, i)
+    t2 = time.perf_counter(); loss.backward()
+    t3 = time.perf_counter(); opt.step()
+    t4 = time.perf_counter()
+    if rec:
+        T["zero"] += t1 - t0; T["train_step"] += t2 - t1; T["backward"] += t3 - t2; T["opt"] += t4 - t3
+for i in range(5): step(i, False)
+torch.cuda.synchronize()
+N = 30
+t0 = time.perf_counter()
+for i in range(N): step(i, True)
+th = time.perf_counter() - t0
+torch.cuda.synchronize()
+tt = time.perf_counter() - t0
+print(f"host loop {1e3*th/N:.2f} ms/step, with final sync {1e3*tt/N:.2f} ms/step")
+print({k: round(1e3 * v / N, 3) for k, v in T.items()})
+# host-only cost: same loop while the GPU is idle at each phase start (sync before each step)
+T = {k: 0.0 for k in T}
+for i in range(N):
+    torch.cuda.synchronize(); step(i, True)
+print("per-phase host cost with idle GPU:", {k: round(1e3 * v / N, 3) for k, v in T.items()})

@@ -228,3 +228,33 @@ def test_authors_resolution_448():
     assert _within(e_hip, e_cpu, CAP_GRAD_FLAT, 2e-5, NOISE_GRAD), (e_hip, e_cpu)
     worst = max(rel_l2(p2.grad, p3.grad) for (_, p2), (_, p3) in zip(net.named_parameters(), ref64.named_parameters()))
     assert worst < CAP_GRAD_TENSOR, worst
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_poisoned_workspace(monkeypatch, dtype):
+    """The workspace arena needs no initialisation: filled with NaN bit patterns before the first call, the
+    forward and backward passes must still be finite and match the oracle (packed-weight padding, statistics
+    slabs, split-K and gradient slabs are all written before they are read)."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd import Unet
+    monkeypatch.setenv("D3F_POISON_WORKSPACE", "1")
+    torch.manual_seed(5)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    net = Unet("resnet34", None, 3, 3, None, compute_dtype=dtype)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().train()
+    x = torch.randn(2, 3, 64, 96)
+    y_ref = ref(x)
+    y_ref.square().mean().backward()
+    for _ in range(2):  # second pass: re-uses the arena after a backward
+        net.zero_grad(set_to_none=True)
+        y = net(x.cuda())
+        y.square().mean().backward()
+        assert torch.isfinite(y).all()
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    cap = CAP_FWD if dtype == "f32" else 0.15
+    assert rel_l2(y.cpu(), y_ref) < cap
+    if dtype == "f32":
+        g = torch.cat([p.grad.flatten().cpu() for p in net.parameters()])
+        g_ref = torch.cat([p.grad.flatten() for p in ref.parameters()])
+        assert rel_l2(g, g_ref) < CAP_GRAD_FLAT
