@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, '/root/repo')
+import sys, os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from denoising_diffusion_deep_fake_amd import ops
 shapes = {
