@@ -265,7 +265,12 @@ struct WTile {
 };
 static WTile pick_wtile(const WgradParams& p) {
   const int cin = p.C0 + p.C1;
-  if (p.Cout >= 128 && cin >= 128) return {128, 128};
+  if (const char* f = getenv("D3F_WGRAD_TILE")) {  // tuning knob
+    const int t = atoi(f);
+    if ((t == 128 || t == 64 || t == 32) && (p.C1 == 0 || p.C0 % t == 0)) return {t, t};
+  }
+  // measured per layer of Unet(resnet34) at B=16, 256x256 (profiles/README.md, r01_h): with ~1024 blocks the
+  // 64x64 tile beats 128x128 on every wide layer (fewer split slabs to write and re-read), by 15-20%
   if (p.Cout > 32 && cin > 32) return {64, 64};
   return {32, 32};
 }
@@ -302,7 +307,9 @@ int wgrad_plan(WgradParams& p, int dtype) {
   p.tiles_ci = cdiv(cin, t.bn);
   const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW;
   const int total_chunks = cdiv(p.M, KP);
-  long splits = (1024 + base - 1) / base;  // aim at ~4 blocks per CU
+  long target = 1024;  // aim at ~4 blocks per CU
+  if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
+  long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
