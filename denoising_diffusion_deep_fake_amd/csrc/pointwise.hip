@@ -194,11 +194,13 @@ int bn_apply_launch(int dtype, const void* y, const float* scale, const float* s
 // BatchNorm backward.  dz = dA * [a > 0];  dbeta = sum dz;  dgamma = sum dz * xhat;
 // dy = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
 // ------------------------------------------------------------------------------------------
-constexpr int BN_BWD_ROWS_PER_BLOCK_MIN = 64;
-
 int bn_bwd_reduce_blocks(long rows, int C, int dtype) {
-  (void)C; (void)dtype;
-  long b = (rows + BN_BWD_ROWS_PER_BLOCK_MIN - 1) / BN_BWD_ROWS_PER_BLOCK_MIN;
+  // a block covers at least one unrolled trip (4 passes of 256 threads) and 16 rows; small tensors then
+  // still spread over enough CUs to hide the load latency
+  const int ve = dtype == D3F_F32 ? 4 : 8;
+  const long per_trip = 4L * (256 / std::max(1, std::min(256, C / ve)));
+  const long min_rows = std::max(16L, per_trip);
+  long b = (rows + min_rows - 1) / min_rows;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
