@@ -9,10 +9,10 @@ import re
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libd3f_hip.so"
+LIB_PATH = Path(os.environ["D3F_LIB"]) if os.environ.get("D3F_LIB") else _HERE / "csrc" / "libd3f_hip.so"  # D3F_LIB: profiling builds
 HEADER_PATH = _HERE.parent / "include" / "d3f_hip.h"
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2  # F32X3: fp32 tensors, contractions on the bf16 matrix pipe (exact 3-way split)
 
 
 class D3FError(RuntimeError):

@@ -50,10 +50,13 @@ struct d3f_unet {
   UnetEngine e;
 };
 
+// storage dtype of a compute dtype (D3F_F32X3 keeps fp32 tensors)
+static inline int sdt(int dtype) { return dtype == D3F_F32X3 ? D3F_F32 : dtype; }
+
 static int desc_check(int dtype, const d3f_conv_desc* d) {
   D3F_CHECK(d != nullptr, "conv: null descriptor");
-  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "conv: dtype %d", dtype);
-  const int ve = dtype == D3F_F32 ? 4 : 8;
+  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16 || dtype == D3F_F32X3, "conv: dtype %d", dtype);
+  const int ve = sdt(dtype) == D3F_F32 ? 4 : 8;
   D3F_CHECK(d->B >= 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: extent");
   D3F_CHECK(d->C0 % ve == 0 && d->C1 % ve == 0, "conv: channels must be multiples of %d", ve);
   D3F_CHECK(d->KH == d->KW && d->KH >= 1 && d->KH <= 7, "conv: kernel %dx%d", d->KH, d->KW);
@@ -67,7 +70,7 @@ struct Geo {
   int Cin, Ho, Wo, CoutPad, Kpad, CoutD, KpadD, CinRows;
 };
 static Geo geo(int dtype, const d3f_conv_desc* d) {
-  const int ve = dtype == D3F_F32 ? 4 : 8, bke = dtype == D3F_F32 ? 32 : 64;
+  const int ve = sdt(dtype) == D3F_F32 ? 4 : 8, bke = sdt(dtype) == D3F_F32 ? 32 : 64;
   Geo g;
   g.Cin = d->C0 + d->C1;
   g.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
@@ -233,7 +236,7 @@ int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float
 size_t d3f_conv_packed_bytes(int dtype, const d3f_conv_desc* d, int which) {
   if (desc_check(dtype, d) != 0) return 0;
   const Geo g = geo(dtype, d);
-  const size_t es = dtype == D3F_F32 ? 4 : 2;
+  const size_t es = dtype == D3F_F32X3 ? 6 : (dtype == D3F_F32 ? 4 : 2);  // x3: three bf16 planes
   return which == 0 ? (size_t)g.CoutPad * g.Kpad * es : (size_t)g.CinRows * g.KpadD * es;
 }
 int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
@@ -282,7 +285,7 @@ static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {
   w.Ho = g.Ho; w.Wo = g.Wo; w.Cout = g.CoutD;
   w.KH = d->KH; w.KW = d->KW; w.stride = d->stride; w.pad = d->pad;
   w.M = d->B * g.Ho * g.Wo;
-  return wgrad_plan(w, dtype);
+  return wgrad_plan(w, sdt(dtype));
 }
 size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d) {
   WgradParams w;
@@ -295,7 +298,7 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
   if (int rc = wgrad_params(dtype, d, w)) return rc;
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
   w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
-  if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
+  if (int rc = wgrad_launch(w, sdt(dtype), (hipStream_t)stream)) return rc;
   return wgrad_reduce_launch(w.partial, w.splits, w.Cout, d->Cout, d->C0 + d->C1, d->CinReal, d->KH, d->KW,
                              dw, 0, (hipStream_t)stream);
 }
@@ -310,11 +313,11 @@ int d3f_bn_finalize(const float* stats, int tiles, int C, int64_t count, const f
 int d3f_bn_apply(int dtype, const void* y, const float* coef, int C, int64_t rows, const void* residual,
                  int relu, void* out, void* stream) {
   D3F_CHECK(y && coef && out, "bn_apply: null argument");
-  return bn_apply_launch(dtype, y, coef + 2 * C, coef + 3 * C, residual, nullptr, nullptr, nullptr, relu,
+  return bn_apply_launch(sdt(dtype), y, coef + 2 * C, coef + 3 * C, residual, nullptr, nullptr, nullptr, relu,
                          out, (long)rows, C, (hipStream_t)stream);
 }
 size_t d3f_bn_backward_workspace_bytes(int dtype, int C, int64_t rows) {
-  return ((size_t)bn_bwd_reduce_blocks((long)rows, C, dtype) * C * 2 + 3 * (size_t)C) * sizeof(float) + 256;
+  return ((size_t)bn_bwd_reduce_blocks((long)rows, C, sdt(dtype)) * C * 2 + 3 * (size_t)C) * sizeof(float) + 256;
 }
 int d3f_bn_backward(int dtype, const void* dA, const void* a_or_null, const void* y, const float* coef,
                     const float* gamma, int C, int64_t rows, void* dy, void* dres, float* dgamma,
@@ -322,38 +325,38 @@ int d3f_bn_backward(int dtype, const void* dA, const void* a_or_null, const void
   D3F_CHECK(dA && y && coef && gamma && dy && dgamma && dbeta && workspace, "bn_backward: null argument");
   hipStream_t s = (hipStream_t)stream;
   float* part = reinterpret_cast<float*>(workspace);
-  const int blocks = bn_bwd_reduce_blocks((long)rows, C, dtype);
+  const int blocks = bn_bwd_reduce_blocks((long)rows, C, sdt(dtype));
   float* k = part + (size_t)round_up((long)blocks * C * 2, 4);
   int nb = 0;
-  if (int rc = bn_bwd_reduce_launch(dtype, dA, a_or_null, y, coef, coef + C, part, &nb, (long)rows, C, s))
+  if (int rc = bn_bwd_reduce_launch(sdt(dtype), dA, a_or_null, y, coef, coef + C, part, &nb, (long)rows, C, s))
     return rc;
   if (int rc = bn_bwd_finalize_launch(part, nb, C, (long)rows, gamma, coef + C, dgamma, dbeta, 0, k, s))
     return rc;
-  return bn_bwd_apply_launch(dtype, dA, a_or_null, y, coef, coef + C, k, dy, dres, 0, (long)rows, C, s);
+  return bn_bwd_apply_launch(sdt(dtype), dA, a_or_null, y, coef, coef + C, k, dy, dres, 0, (long)rows, C, s);
 }
 
 int d3f_maxpool3x3s2_forward(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
                              int C, void* stream) {
   D3F_CHECK(in && out && idx, "maxpool: null argument");
-  return maxpool3x3s2_fwd_launch(dtype, in, out, idx, B, H, W, C, (hipStream_t)stream);
+  return maxpool3x3s2_fwd_launch(sdt(dtype), in, out, idx, B, H, W, C, (hipStream_t)stream);
 }
 int d3f_maxpool3x3s2_backward(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
                               int B, int H, int W, int C, void* stream) {
   D3F_CHECK(dout && idx && din, "maxpool: null argument");
-  return maxpool3x3s2_bwd_launch(dtype, dout, idx, din, accumulate, B, H, W, C, (hipStream_t)stream);
+  return maxpool3x3s2_bwd_launch(sdt(dtype), dout, idx, din, accumulate, B, H, W, C, (hipStream_t)stream);
 }
 int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int Hlow, int Wlow, int C,
                             void* stream) {
   D3F_CHECK(dfull && dlow, "upsample2x_backward: null argument");
-  return sum2x2_launch(dtype, dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
+  return sum2x2_launch(sdt(dtype), dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
 }
 int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream) {
   D3F_CHECK(in && out && Cpad >= C, "nchw_to_nhwc: argument");
-  return nchw_to_nhwc_launch(dtype, in, out, B, C, H, W, Cpad, (hipStream_t)stream);
+  return nchw_to_nhwc_launch(sdt(dtype), in, out, B, C, H, W, Cpad, (hipStream_t)stream);
 }
 int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad, void* stream) {
   D3F_CHECK(in && out && Cpad >= C, "nhwc_to_nchw: argument");
-  return nhwc_to_nchw_launch(dtype, in, out, B, C, H, W, Cpad, (hipStream_t)stream);
+  return nhwc_to_nchw_launch(sdt(dtype), in, out, B, C, H, W, Cpad, (hipStream_t)stream);
 }
 
 // ---- training-step arithmetic ---------------------------------------------------------------

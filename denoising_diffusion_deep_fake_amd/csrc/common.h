@@ -21,6 +21,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef D3F_F32
 #define D3F_F32 0  // same values as include/d3f_hip.h
 #define D3F_BF16 1
+#define D3F_F32X3 2  // fp32 storage; contractions on the bf16 matrix pipe from an exact 3-way split
 #endif
 namespace d3f {
 

@@ -83,30 +83,112 @@ template <> struct Mma<bf16_t, 16> {
   }
 };
 
+// fp32 contraction on the bf16 matrix pipe ("x3" mode).  Every fp32 operand is split EXACTLY into three
+// bf16 terms x = h + m + l (truncation splits: 8 + 8 + 8 significand bits) when its tile is staged in LDS, and
+//   a*b ~= al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh
+// is accumulated in fp32 by six bf16 MFMAs (the three dropped terms are <= 2^-24 |a*b|, below the fp32
+// rounding of the accumulation itself; measured error vs float64 equals v_mfma_f32's,
+// profiles/microbench/split_bench.hip).  Six bf16 MFMAs take 6/16 of the time of the fp32 MFMAs they replace.
+#ifndef D3F_X3_ABLATE
+#define D3F_X3_ABLATE 0  // timing-only ablations (wrong results): 1 no split VALU, 2 one MFMA of six, 3 one plane of fragment reads
+#endif
+template <int MT> struct MmaX3;
+template <> struct MmaX3<32> {
+  using Acc = f32x16;
+  static constexpr int NREG = 16;
+  static constexpr int NINST = 6;
+  static __device__ __forceinline__ void one(Acc& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4 (&a)[3], const uint4 (&b)[3], F&& after) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
+#pragma unroll
+    for (int t = (D3F_X3_ABLATE == 2 ? 5 : 0); t < 6; ++t) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a[PA[t]]),
+                                                  *reinterpret_cast<const bf16x8*>(&b[PB[t]]), c, 0, 0, 0);
+      after();
+    }
+  }
+};
+template <> struct MmaX3<16> {
+  using Acc = f32x4;
+  static constexpr int NREG = 4;
+  static constexpr int NINST = 6;
+  static __device__ __forceinline__ void one(Acc& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+  template <typename F>
+  static __device__ __forceinline__ void run(Acc& c, const uint4 (&a)[3], const uint4 (&b)[3], F&& after) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[PA[t]]),
+                                                  *reinterpret_cast<const bf16x8*>(&b[PB[t]]), c, 0, 0, 0);
+      after();
+    }
+  }
+};
+
+// 4 fp32 -> three 8-byte groups of bf16 (exact 3-way truncation split; v_perm_b32 packs two high halves)
+__device__ __forceinline__ void split3x4(const uint4& v, uint2& h, uint2& m, uint2& l) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t r1[4], r2[4];
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {  // two elements per v_pk_add_f32
+    const f32x2 f = {__uint_as_float(x[e]), __uint_as_float(x[e + 1])};
+    const f32x2 hi = {__uint_as_float(x[e] & 0xffff0000u), __uint_as_float(x[e + 1] & 0xffff0000u)};
+    const f32x2 a = f - hi;
+    r1[e] = __float_as_uint(a.x);
+    r1[e + 1] = __float_as_uint(a.y);
+    const f32x2 mid = {__uint_as_float(r1[e] & 0xffff0000u), __uint_as_float(r1[e + 1] & 0xffff0000u)};
+    const f32x2 b = a - mid;
+    r2[e] = __float_as_uint(b.x);
+    r2[e + 1] = __float_as_uint(b.y);
+  }
+  constexpr uint32_t SEL = 0x07060302u;  // {lo.b2, lo.b3, hi.b2, hi.b3}
+  h = make_uint2(__builtin_amdgcn_perm(x[1], x[0], SEL), __builtin_amdgcn_perm(x[3], x[2], SEL));
+  m = make_uint2(__builtin_amdgcn_perm(r1[1], r1[0], SEL), __builtin_amdgcn_perm(r1[3], r1[2], SEL));
+  l = make_uint2(__builtin_amdgcn_perm(r2[1], r2[0], SEL), __builtin_amdgcn_perm(r2[3], r2[2], SEL));
+}
+
 constexpr int LDS_ROW = 36;  // dwords per LDS row: 128 B of data + 16 B pad
+constexpr int X3_ROW = 16;   // x3 mode: dwords per LDS row of one bf16 plane (32 bf16, XOR-swizzled, no pad)
 
 // SMALLC: Cin < one k-row (taps decoded per lane).  FAST: plain gather (one source, no up-sampling /
 // zero insertion, <= 32 taps): per-row base offset + tap-validity bitmask are computed once, so a
 // k-tile costs ~4 VALU per gathered vector.  This matters because the f32 MFMA runs at the f32 VALU
 // rate and VALU time ADDS to it (microbenchmark in profiles/README.md): VALU per MFMA is the lever.
-template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, bool FAST>
+template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, bool FAST, bool X3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int VE = Elem<T>::VE, BKE = Elem<T>::BKE;
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / MT, FN = TN / MT;
   constexpr int NVA = BM * 8 / 256;
-  constexpr int NVB = (BN * 8 + 255) / 256;
-  constexpr int NS = (MT == 32) ? 4 : 2;  // fragment reads per k-tile
+  // weight pieces per thread: a k-tile row is 8 x 16 B (f32 / bf16), or -- x3: the weights are pre-split at pack
+  // time into three bf16 planes -- 3 planes x 4 x 16 B
+  constexpr int NVB = X3 ? (BN * 12 + 255) / 256 : (BN * 8 + 255) / 256;
+  constexpr unsigned WSTEP = X3 ? 64u : (unsigned)(Elem<T>::BKE * sizeof(T));  // bytes per k-tile in a weight row
+  // fragment reads per k-tile (x3: a k-tile of 32 is two 32x32x16 or one 16x16x32 step)
+  constexpr int NS = X3 ? ((MT == 32) ? 2 : 1) : ((MT == 32) ? 4 : 2);
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(TM % MT == 0 && TN % MT == 0, "wave tile");
-  using M_ = Mma<T, MT>;
+  static_assert(!X3 || sizeof(T) == 4, "x3 mode splits fp32 operands");
+  using M_ = std::conditional_t<X3, MmaX3<MT>, Mma<T, MT>>;
   using Acc = typename M_::Acc;
 
   // two LDS stages (tile t is read by the MFMAs while tile t+1 is written and tile t+2 is loaded),
   // except for the 256-row tiles of the narrow layers: 2 x 41 KB would leave one workgroup per CU
-  constexpr bool DB = BM < 256;
+  // (x3, 128x128: three bf16 planes per operand make a stage 48 KB -- one stage, three workgroups per CU)
+  constexpr bool DB = BM < 256 && !(X3 && BM == 128 && BN == 128);
   constexpr int NSTAGE = DB ? 2 : 1;
-  constexpr int STAGE = (BM + BN) * LDS_ROW;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[NSTAGE * STAGE];
+  constexpr int STAGE = X3 ? 3 * (BM + BN) * X3_ROW : (BM + BN) * LDS_ROW;
+  constexpr int APL = BM * X3_ROW, BPL = BN * X3_ROW;  // x3: dwords per plane
+  constexpr int CTILE = BM * (BN + 4);  // epilogue: the fp32 C tile is staged through the same memory
+  constexpr int LDS_DW = NSTAGE * STAGE > CTILE ? NSTAGE * STAGE : CTILE;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -185,13 +267,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.src0, p.src0_bytes);
   const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
-  const int w_row_bytes = p.Kpad * (int)sizeof(T);
+  const int w_row_bytes = X3 ? p.Kpad * 2 : p.Kpad * (int)sizeof(T);
   unsigned woff[NVB];
+  int x3_bdst[NVB];  // x3: LDS dword offset of this thread's weight pieces inside the B planes (-1: no piece)
 #pragma unroll
   for (int j = 0; j < NVB; ++j) {
-    const int row = rbase + 32 * j;
-    const int n = n0 + row;
-    woff[j] = (row < BN && n < p.CoutPad) ? (unsigned)(n * w_row_bytes + chunk * 16) : BUF_OOB;
+    if constexpr (X3) {
+      const int slot = j * 256 + tid, plane = slot / (BN * 4), within = slot % (BN * 4);
+      const int row = within >> 2, c = within & 3, n = n0 + row;
+      const bool ok = slot < 3 * BN * 4;
+      woff[j] = (ok && n < p.CoutPad) ? (unsigned)(plane * (p.CoutPad * w_row_bytes) + n * w_row_bytes + c * 16) : BUF_OOB;
+      x3_bdst[j] = ok ? plane * BPL + row * X3_ROW + ((c ^ ((row >> 2) & 3)) << 2) : -1;
+    } else {
+      const int row = rbase + 32 * j;
+      const int n = n0 + row;
+      woff[j] = (row < BN && n < p.CoutPad) ? (unsigned)(n * w_row_bytes + chunk * 16) : BUF_OOB;
+      x3_bdst[j] = 0;
+    }
   }
 
   uint4 ra[NVA], rb[NVB];
@@ -258,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     } else {
       // an out-of-range row keeps bit 31 set after the add (descriptors cover < 2 GiB): no select
       constexpr int j = q - NVA;
-      rb[j] = buf_load16(rw, woff[j] + (unsigned)(x.kt * BKE) * (unsigned)sizeof(T));
+      rb[j] = buf_load16(rw, woff[j] + (unsigned)x.kt * WSTEP);
     }
   };
   auto load_tile = [&](int kt) {
@@ -270,18 +362,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const int fr = (MT == 32) ? (lane & 31) : (lane & 15);
   const int fq = (MT == 32) ? (lane >> 5) : (lane >> 4);
-  auto stage = [&](int buf) {
-    uint32_t* As = lds + buf * STAGE;
-    uint32_t* Bs = As + BM * LDS_ROW;
-#pragma unroll
-    for (int i = 0; i < NVA; ++i)
-      *reinterpret_cast<uint4*>(&As[(rbase + 32 * i) * LDS_ROW + chunk * 4]) = ra[i];
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int row = rbase + 32 * j;
-      if (BN >= 32 || row < BN) *reinterpret_cast<uint4*>(&Bs[row * LDS_ROW + chunk * 4]) = rb[j];
+  // x3: this thread's 8 bytes inside a 64-byte plane row; 16-byte chunks are XOR-swizzled with bits 2..3 of the
+  // row so that both the ds_write_b64 of a half-wave (4 rows) and the ds_read_b128 of 16 fragment rows are
+  // bank-conflict free without padding
+  const int x3_wcol = (((chunk >> 1) ^ ((rbase >> 2) & 3)) << 2) + ((chunk & 1) << 1);
+  auto put = [&](uint32_t* opbase, int plane, int row, const uint4& v) {
+    if constexpr (X3) {
+      uint2 h, m, l;
+      if constexpr (D3F_X3_ABLATE == 1) { h = make_uint2(v.x, v.y); m = make_uint2(v.z, v.w); l = h; }
+      else split3x4(v, h, m, l);
+      uint32_t* d = opbase + row * X3_ROW + x3_wcol;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + plane) = m;
+      *reinterpret_cast<uint2*>(d + 2 * plane) = l;
+    } else {
+      *reinterpret_cast<uint4*>(&opbase[row * LDS_ROW + chunk * 4]) = v;
     }
   };
+  auto stage_regs = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB]) {
+    uint32_t* As = lds + buf * STAGE;
+    uint32_t* Bs = As + (X3 ? 3 * APL : BM * LDS_ROW);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) put(As, APL, rbase + 32 * i, A[i]);
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      if constexpr (X3) {
+        if ((3 * BN * 4) % 256 == 0 || x3_bdst[j] >= 0) *reinterpret_cast<uint4*>(&Bs[x3_bdst[j]]) = Bv[j];
+      } else {
+        const int row = rbase + 32 * j;
+        if (BN >= 32 || row < BN) put(Bs, BPL, row, Bv[j]);
+      }
+    }
+  };
+  auto stage = [&](int buf) { stage_regs(buf, ra, rb); };
 
   // Software pipeline, ONE barrier per k-tile: in iteration t the registers hold tile t+1 (loaded
   // during iteration t-1); they are written to the other LDS stage, the loads of tile t+2 are issued,
@@ -290,8 +403,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // compute(buf, hook): hook(n) runs behind the n-th MFMA instruction of the k-tile
   auto compute = [&](int buf, auto&& hook) {
     const uint32_t* As = lds + buf * STAGE;
-    const uint32_t* Bs = As + BM * LDS_ROW;
     int n = 0;
+    if constexpr (X3) {
+      const uint32_t* Bs = As + 3 * APL;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c16 = ((MT == 32) ? (2 * s + fq) : fq) ^ ((fr >> 2) & 3);
+        uint4 a[FM][3], b[FN][3];
+#pragma unroll
+        for (int pl = 0; pl < (D3F_X3_ABLATE == 3 ? 1 : 3); ++pl) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            a[i][pl] = *reinterpret_cast<const uint4*>(&As[pl * APL + (wm * TM + i * MT + fr) * X3_ROW + c16 * 4]);
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            b[j][pl] = *reinterpret_cast<const uint4*>(&Bs[pl * BPL + (wn * TN + j * MT + fr) * X3_ROW + c16 * 4]);
+        }
+        if constexpr (D3F_X3_ABLATE == 3) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) a[i][1] = a[i][2] = a[i][0];
+#pragma unroll
+          for (int j = 0; j < FN; ++j) b[j][1] = b[j][2] = b[j][0];
+        }
+        // product index outermost: consecutive MFMAs go to different accumulators (a chain of dependent
+        // 8-pass MFMAs on one accumulator runs at about half rate)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
+#pragma unroll
+        for (int t = (D3F_X3_ABLATE == 2 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              if constexpr (std::is_same_v<M_, MmaX3<MT>>) M_::one(acc[i][j], a[i][PA[t]], b[j][PB[t]]);
+              hook(n++);
+            }
+      }
+    } else {
+    const uint32_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int ch = (MT == 32) ? (2 * s + fq) : (4 * s + fq);
@@ -306,6 +454,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) M_::run(acc[i][j], a[i], b[j], [&]() { hook(n++); });
+    }
     }
   };
   auto no_hook = [](int) {};
@@ -333,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // loads that get only one compute phase to land cost 20 %.  Here the scalar state is incremental --
     // with one NHWC source the byte offset of a k-tile advances by 128 per tile and jumps once per filter
     // row -- and two register sets keep the loads of tiles t+2 and t+3 in flight while tile t computes.
-    const unsigned step_bytes = BKE * (unsigned)sizeof(T);
+    const unsigned step_bytes = BKE * (unsigned)sizeof(T);  // activations; weights advance by WSTEP
     const int cpt = Cin / BKE;                                        // k-tiles per tap
     const unsigned rowjump = (unsigned)((p.Wv - p.KW) * p.C0) * (unsigned)sizeof(T);
     unsigned ld_delta, ld_bit, ld_w;                                  // state of the LOAD stream (runs ahead)
@@ -345,7 +494,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ld_bit = (unsigned)tap0;
       ld_cleft = cpt - c0;
       ld_kwleft = p.KW - kw0;
-      ld_w = (unsigned)kt_begin * step_bytes;
+      ld_w = (unsigned)kt_begin * WSTEP;
     }
     uint4 ra2[NVA], rb2[NVB];  // second register set
     auto issue_piece = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB], auto qc) {
@@ -357,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }
     };
     auto advance = [&]() {  // branch-free, ~10 SALU
-      ld_w += step_bytes;
+      ld_w += WSTEP;
       ld_delta += step_bytes;
       const int tapwrap = (--ld_cleft == 0) ? 1 : 0;
       ld_cleft = tapwrap ? cpt : ld_cleft;
@@ -373,14 +522,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }(std::make_integer_sequence<int, NVA + NVB>{});
       advance();
     };
-    auto stage_set = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB]) {
-      uint32_t* As = lds + buf * STAGE;
-      uint32_t* Bs = As + BM * LDS_ROW;
-#pragma unroll
-      for (int i = 0; i < NVA; ++i) *reinterpret_cast<uint4*>(&As[(rbase + 32 * i) * LDS_ROW + chunk * 4]) = A[i];
-#pragma unroll
-      for (int j = 0; j < NVB; ++j) *reinterpret_cast<uint4*>(&Bs[(rbase + 32 * j) * LDS_ROW + chunk * 4]) = Bv[j];
-    };
+    auto stage_set = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB]) { stage_regs(buf, A, Bv); };
     constexpr int NMF = NS * FM * FN * M_::NINST;
     constexpr int NPC = NVA + NVB;
     constexpr int EV = (NMF / NPC) > 0 ? (NMF / NPC) : 1;
@@ -396,6 +538,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }(std::make_integer_sequence<int, NPC>{});
       advance();
     };
+    // x3: the split arithmetic + LDS writes of the NEXT tile are emitted piece by piece behind the MFMAs as
+    // well (each piece is staged, then its registers are re-issued), instead of in front of the MFMA block
+    auto stage_piece = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB], auto qc) {
+      constexpr int q = decltype(qc)::value;
+      uint32_t* As = lds + buf * STAGE;
+      if constexpr (q < NVA) {
+        put(As, APL, rbase + 32 * q, A[q]);
+      } else {
+        constexpr int j = q - NVA;
+        uint32_t* Bs = As + 3 * APL;
+        if ((3 * BN * 4) % 256 == 0 || x3_bdst[j] >= 0) *reinterpret_cast<uint4*>(&Bs[x3_bdst[j]]) = Bv[j];
+      }
+    };
+    auto compute_stage_issue = [&](int cbuf, int sbuf, uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
+      compute(cbuf, [&](int n) {
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+          ((n == Q * EV ? (stage_piece(sbuf, A, Bv, std::integral_constant<int, Q>{}),
+                           issue_piece(A, Bv, std::integral_constant<int, Q>{}), 0) : 0), ...);
+        }(std::make_integer_sequence<int, NPC>{});
+      });
+      [&]<int... Q>(std::integer_sequence<int, Q...>) {
+        ((Q * EV >= NMF ? (stage_piece(sbuf, A, Bv, std::integral_constant<int, Q>{}),
+                           issue_piece(A, Bv, std::integral_constant<int, Q>{}), 0) : 0), ...);
+      }(std::make_integer_sequence<int, NPC>{});
+      advance();
+    };
     const int n = kt_end - kt_begin;
     // prologue: tiles 0, 1 in flight; tile 0 staged; tile 2 in flight in the freed set
     issue_all(ra, rb);
@@ -407,12 +575,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // steady state, unrolled by two so that LDS stage and register set are static:
     //   iteration t: stage tile t+1 (set (t+1)&1), re-issue that set with tile t+3, compute tile t
     for (; t + 4 < n; t += 2) {
-      stage_set(1, ra2, rb2);        // tile t+1
-      compute_issue(0, ra2, rb2);    // tile t; loads of tile t+3 -> set 1
-      __syncthreads();
-      stage_set(0, ra, rb);          // tile t+2
-      compute_issue(1, ra, rb);      // tile t+1; loads of tile t+4 -> set 0
-      __syncthreads();
+      if constexpr (X3) {
+        compute_stage_issue(0, 1, ra2, rb2);  // tile t; stages tile t+1, loads of tile t+3 -> set 1
+        __syncthreads();
+        compute_stage_issue(1, 0, ra, rb);    // tile t+1; stages tile t+2, loads of tile t+4 -> set 0
+        __syncthreads();
+      } else {
+        stage_set(1, ra2, rb2);        // tile t+1
+        compute_issue(0, ra2, rb2);    // tile t; loads of tile t+3 -> set 1
+        __syncthreads();
+        stage_set(0, ra, rb);          // tile t+2
+        compute_issue(1, ra, rb);      // tile t+1; loads of tile t+4 -> set 0
+        __syncthreads();
+      }
     }
     for (; t < n; ++t) {             // tail (at most 4 tiles): same schedule with bounds checks
       const int cur = t & 1;
@@ -498,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // dimension -- 4x fewer store instructions than one dword per accumulator register, and the
   // per-channel statistics are column sums of the staged tile.
   constexpr int LDC = BN + 4;
-  static_assert(BM * LDC <= NSTAGE * STAGE, "C tile must fit in the LDS stages");
+  static_assert(BM * LDC <= LDS_DW, "C tile must fit in the LDS allocation");
   float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -694,7 +869,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 // host side: tile selection + launch
 // ---------------------------------------------------------------------------------------
 static bool is_small_c(const ConvParams& p, int dtype) {
-  const int bke = dtype == D3F_F32 ? 32 : 64;
+  const int bke = dtype == D3F_BF16 ? 64 : 32;
   return ((p.C0 + p.C1) % bke) != 0;
 }
 
@@ -711,7 +886,7 @@ static bool forced_tile(int* bm, int* bn, int* sk) {
   return on;
 }
 
-static ConvTile pick_tile(const ConvParams& p) {
+static ConvTile pick_tile(const ConvParams& p, bool x3) {
   const int co = p.Cout;
   int fbm, fbn, fsk;
   if (forced_tile(&fbm, &fbn, &fsk) && co >= 64) return {fbm, fbn};
@@ -730,9 +905,9 @@ size_t conv_splitk_floats(const ConvParams& p) {
 }
 
 int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
-  const int ve = dtype == D3F_F32 ? 4 : 8;
-  const int bke = dtype == D3F_F32 ? 32 : 64;
-  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "conv: bad dtype %d", dtype);
+  const int ve = dtype == D3F_BF16 ? 8 : 4;
+  const int bke = dtype == D3F_BF16 ? 64 : 32;
+  D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16 || dtype == D3F_F32X3, "conv: bad dtype %d", dtype);
   D3F_CHECK((p.C0 % ve) == 0 && (p.C1 % ve) == 0, "conv: channels (%d,%d) not a multiple of %d",
             p.C0, p.C1, ve);
   D3F_CHECK(p.Kpad % bke == 0 && p.Kpad >= p.KH * p.KW * (p.C0 + p.C1),
@@ -750,12 +925,12 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0, "conv: Cout=%d must be a multiple of 4 (vector epilogue)", p.Cout);
   D3F_CHECK(p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0, "conv: out_c0=%d must be a multiple of 4", p.out_c0);
   D3F_CHECK(p.C1 == 0 || (p.C0 % bke) == 0, "conv: C0=%d must be a multiple of %d when a second source is concatenated", p.C0, bke);
-  const long es = dtype == D3F_F32 ? 4 : 2;
+  const long es = dtype == D3F_BF16 ? 2 : 4;
   const long b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es, b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
-  const long bw = (long)p.CoutPad * p.Kpad * es;
+  const long bw = dtype == D3F_F32X3 ? (long)p.CoutPad * p.Kpad * 6 : (long)p.CoutPad * p.Kpad * es;
   D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
-  const ConvTile t = pick_tile(p);
+  const ConvTile t = pick_tile(p, dtype == D3F_F32X3);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
   p.splitk = 1;
@@ -783,30 +958,30 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   return 0;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MT>
+template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool X3>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk), block(256);
   static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
   const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
   if (smallc)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true, false, X3>), grid, block, 0, stream, p);
   else if (fast)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, true, X3>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, false, X3>), grid, block, 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }
 
-template <typename T> static int launch_t(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const ConvTile t = pick_tile(p);
+template <typename T, bool X3> static int launch_t(const ConvParams& p, bool smallc, hipStream_t stream) {
+  const ConvTile t = pick_tile(p, X3);
   D3F_CHECK(p.tiles_m == cdiv(p.M, t.BM) && p.tiles_n == cdiv(p.Cout, t.BN),
             "conv: params were not planned (tiles %d,%d)", p.tiles_m, p.tiles_n);
-  if (t.BM == 256 && t.BN == 16) return launch_cfg<T, 256, 16, 4, 1, 16>(p, smallc, stream);
-  if (t.BM == 256 && t.BN == 32) return launch_cfg<T, 256, 32, 4, 1, 32>(p, smallc, stream);
-  if (t.BM == 128 && t.BN == 128) return launch_cfg<T, 128, 128, 2, 2, 32>(p, smallc, stream);
-  if (t.BM == 128 && t.BN == 64) return launch_cfg<T, 128, 64, 2, 2, 32>(p, smallc, stream);
-  return launch_cfg<T, 64, 64, 2, 2, 32>(p, smallc, stream);
+  if (t.BM == 256 && t.BN == 16) return launch_cfg<T, 256, 16, 4, 1, 16, X3>(p, smallc, stream);
+  if (t.BM == 256 && t.BN == 32) return launch_cfg<T, 256, 32, 4, 1, 32, X3>(p, smallc, stream);
+  if (t.BM == 128 && t.BN == 128) return launch_cfg<T, 128, 128, 2, 2, 32, X3>(p, smallc, stream);
+  if (t.BM == 128 && t.BN == 64) return launch_cfg<T, 128, 64, 2, 2, 32, X3>(p, smallc, stream);
+  return launch_cfg<T, 64, 64, 2, 2, 32, X3>(p, smallc, stream);
 }
 
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
@@ -825,10 +1000,12 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);
   if (prof) prof_begin(prof_cls, q.flops, stream);
-  int rc = dtype == D3F_F32 ? launch_t<float>(q, smallc, stream) : launch_t<bf16_t>(q, smallc, stream);
+  int rc = dtype == D3F_F32X3 ? launch_t<float, true>(q, smallc, stream)
+           : dtype == D3F_F32 ? launch_t<float, false>(q, smallc, stream)
+                              : launch_t<bf16_t, false>(q, smallc, stream);
   if (rc == 0 && q.splitk > 1) {
     const dim3 grid((unsigned)cdiv(q.M, SK_ROWS)), block(256);
-    if (dtype == D3F_F32)
+    if (dtype != D3F_BF16)
       hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, grid, block, 0, stream, q);
     else
       hipLaunchKernelGGL(conv_splitk_reduce_kernel<bf16_t>, grid, block, 0, stream, q);

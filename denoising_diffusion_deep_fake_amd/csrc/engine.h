@@ -86,11 +86,13 @@ class UnetEngine {
   int num_segments = 4;
   long seg_grad_begin[8] = {0}, seg_grad_end[8] = {0};
   int B = 0, H = 0, W = 0, dtype = 0, in_channels = 3, classes = 3;
+  int cdtype = 0;  // contraction dtype handed to the conv kernels (dtype = storage dtype; differs for D3F_F32X3)
   double fwd_flops = 0, bwd_flops = 0;  // algorithmic conv FLOPs (2*MAC) per call
   std::vector<Unit> units;
 
  private:
   int esize() const { return dtype == D3F_F32 ? 4 : 2; }
+  int wsize() const { return cdtype == D3F_F32X3 ? 6 : esize(); }  // bytes per packed weight (x3: three bf16 planes)
   int ve() const { return dtype == D3F_F32 ? 4 : 8; }
   int bke() const { return dtype == D3F_F32 ? 32 : 64; }
   int new_tensor(int H_, int W_, int C_);

@@ -135,12 +135,12 @@ int UnetEngine::add_unit(const std::string& conv_name, const std::string& bn_nam
   }
   u.CoutPad = (int)round_up(Cout, 16);
   u.Kpad = (int)round_up((long)k * k * u.Cin(), bke());
-  u.wf_off = alloc((size_t)u.CoutPad * u.Kpad * esize());
+  u.wf_off = alloc((size_t)u.CoutPad * u.Kpad * wsize());
   u.CoutD = (int)round_up(Cout, ve());
   if (u.need_dgrad) {
     u.KpadD = (int)round_up((long)k * k * u.CoutD, bke());
     u.CinRows = (int)round_up(u.Cin(), 16);
-    u.wd_off = alloc((size_t)u.CinRows * u.KpadD * esize());
+    u.wd_off = alloc((size_t)u.CinRows * u.KpadD * wsize());
   }
   units.push_back(u);
   return (int)units.size() - 1;
@@ -155,7 +155,7 @@ int UnetEngine::plan_unit(Unit& u) {
   f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;
   f.M = B * u.Ho * u.Wo;
   f.mode = u.bn ? CONV_RAW_STATS : CONV_HEAD_NCHW;
-  if (int rc = conv_igemm_plan(f, dtype, true)) return rc;
+  if (int rc = conv_igemm_plan(f, cdtype, true)) return rc;
   if (conv_splitk_floats(f) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(f) * sizeof(float);
   const double macs = (double)f.M * u.Cout * u.KH * u.KW * u.CinReal;
   f.flops = 2.0 * macs;
@@ -198,7 +198,7 @@ int UnetEngine::plan_unit(Unit& u) {
     d.M = B * u.Hv * u.Wv;
     d.mode = CONV_DGRAD;
     d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
-    if (int rc = conv_igemm_plan(d, dtype, true)) return rc;
+    if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
     if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
     d.flops = 2.0 * macs;
     bwd_flops += 2.0 * macs;
@@ -212,7 +212,7 @@ int UnetEngine::plan_unit(Unit& u) {
 
 int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B_, int H_, int W_,
                       int dtype_) {
-  D3F_CHECK(dtype_ == D3F_F32 || dtype_ == D3F_BF16, "unet: dtype %d", dtype_);
+  D3F_CHECK(dtype_ == D3F_F32 || dtype_ == D3F_BF16 || dtype_ == D3F_F32X3, "unet: dtype %d", dtype_);
   D3F_CHECK(B_ >= 1 && H_ >= 32 && W_ >= 32, "unet: bad shape B=%d H=%d W=%d", B_, H_, W_);
   D3F_CHECK(H_ % 32 == 0 && W_ % 32 == 0,
             "Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.",
@@ -223,7 +223,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   if (std::strcmp(encoder, "resnet34") == 0) { nblocks[0] = 3; nblocks[1] = 4; nblocks[2] = 6; nblocks[3] = 3; }
   else if (std::strcmp(encoder, "resnet18") == 0) { nblocks[0] = nblocks[1] = nblocks[2] = nblocks[3] = 2; }
   else return set_error(-1, "Wrong encoder name `%s`, supported encoders: ['resnet18', 'resnet34']", encoder);
-  B = B_; H = H_; W = W_; dtype = dtype_; in_channels = in_channels_; classes = classes_;
+  B = B_; H = H_; W = W_; cdtype = dtype_; dtype = dtype_ == D3F_F32X3 ? D3F_F32 : dtype_; in_channels = in_channels_; classes = classes_;
   D3F_CHECK((long)B * H * W * 64 < (1L << 31), "unet: activation too large for 32-bit pixel indices");
 
   // ---- graph --------------------------------------------------------------------------
@@ -423,7 +423,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     e.ctiles = (uint16_t)((crows + CT - 1) / CT);
     blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
   }
-  return pack_all_launch(dtype, params_, ws_, t, (int)blocks, s);
+  return pack_all_launch(cdtype, params_, ws_, t, (int)blocks, s);
 }
 
 static inline float* coef_ptr(char* ws, const Unit& u, int which) {
@@ -461,7 +461,7 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
       p.mode = CONV_HEAD_NCHW;
       p.out0 = out;
       p.scale = params_ + u.bias_off;
-      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+      if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
       continue;
     }
     const Unit* ds = u.res_unit >= 0 ? &units[u.res_unit] : nullptr;
@@ -470,7 +470,7 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
       p.out0 = T(u.y);
       p.stats = reinterpret_cast<float*>(ws + stats_off);
       p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
-      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+      if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
       if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, (long)p.M,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
@@ -496,7 +496,7 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
         p.out0 = T(u.y);  // downsample branch: bn(conv(x)) lands in its y slot
         p.res = nullptr;
       }
-      if (int rc = conv_igemm_launch(p, dtype, s)) return rc;
+      if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
     }
   }
   return 0;
@@ -621,7 +621,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
       d.acc1 = op.acc1 ? 1 : 0;
       d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
-      if (int rc = conv_igemm_launch(d, dtype, s)) return rc;
+      if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
     }
   }
   if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream

@@ -641,7 +641,23 @@ int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int
 // ------------------------------------------------------------------------------------------
 // forward:  wf[n][(kh*KW + kw)*Cin + c]                     = w[n][c][kh][kw]
 // dgrad:    wd[c][((KH-1-kh)*KW + (KW-1-kw))*CoutD + n]     = w[n][c][kh][kw]
-template <typename T>
+// store one packed weight: plain T, or (X3) its exact 3-way bf16 split into three planes `plane` elements apart
+template <typename T, bool X3>
+__device__ __forceinline__ void pack_store(T* __restrict__ base, long idx, long plane, float v) {
+  if constexpr (X3) {
+    const uint32_t xb = __float_as_uint(v), hb = xb & 0xffff0000u;
+    const float r1 = v - __uint_as_float(hb);
+    const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    base[idx] = (T)(hb >> 16);
+    base[plane + idx] = (T)(mb >> 16);
+    base[2 * plane + idx] = (T)(__float_as_uint(r2) >> 16);  // exact: r2 has at most 8 significant bits
+  } else {
+    base[idx] = from_f32<T>(v);
+  }
+}
+
+template <typename T, bool X3>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int Cout,
                                                            int CinReal, int Cin, int KH, int KW,
                                                            T* __restrict__ wf, int CoutPad, int Kpad,
@@ -656,14 +672,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
       const int tap = k / Cin, c = k % Cin;
       float v = 0.f;
       if (n < Cout && tap < taps && c < CinReal) v = w[((long)n * CinReal + c) * taps + tap];
-      wf[i] = from_f32<T>(v);
+      pack_store<T, X3>(wf, i, nf, v);
     } else {
       const long j = i - nf;
       const int c = (int)(j / KpadD), k = (int)(j % KpadD);
       const int tapf = k / CoutD, n = k % CoutD;
       float v = 0.f;
       if (c < CinReal && tapf < taps && n < Cout) v = w[((long)n * CinReal + c) * taps + (taps - 1 - tapf)];
-      wd[j] = from_f32<T>(v);
+      pack_store<T, X3>(wd, j, nd, v);
     }
   }
 }
@@ -671,17 +687,20 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Cin, int KH, int KW,
                         void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
                         hipStream_t stream) {
-  const int ve = dtype == D3F_F32 ? 4 : 8;
+  const int ve = dtype == D3F_BF16 ? 8 : 4;
   const int CoutD = (int)round_up(Cout, ve);
   const long total = (wf ? (long)CoutPad * Kpad : 0) + (wd ? (long)CinRows * KpadD : 0);
   if (total == 0) return 0;
   D3F_CHECK(!wf || Kpad >= KH * KW * Cin, "pack: Kpad");
   D3F_CHECK(!wd || KpadD >= KH * KW * CoutD, "pack: KpadD");
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
+    hipLaunchKernelGGL((pack_weights_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
                        CinReal, Cin, KH, KW, (float*)wf, CoutPad, Kpad, (float*)wd, CinRows, CoutD, KpadD);
+  else if (dtype == D3F_F32X3)
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
+                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
   else
-    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
                        CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
   D3F_HIP(hipGetLastError());
   return 0;
@@ -692,7 +711,7 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
 // tile through LDS: the torch layout [n][c][tap] is read in contiguous runs of CT*taps floats and both packed
 // layouts ([n][tap][c] and [c][flipped tap][n]) are written in contiguous runs; padding rows/columns of the
 // packed matrices are (re)written as zeros by the edge tiles, so the workspace needs no initialisation.
-template <typename T>
+template <typename T, bool X3>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ params, char* __restrict__ ws,
                                                        PackTable t) {
   __shared__ float tile[PACK_NT * (PACK_LDS_ROW + 1)];
@@ -721,13 +740,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
     const int cl = i % CT, tap = (i / CT) % taps, nl = i / run;
     const int n = n0 + nl, c = c0 + cl;
-    if (n < CoutPad && c < Cin) wf[(long)n * Kpad + tap * Cin + c] = from_f32<T>(tile[nl * stride + cl * taps + tap]);
+    if (n < CoutPad && c < Cin)
+      pack_store<T, X3>(wf, (long)n * Kpad + tap * Cin + c, (long)CoutPad * Kpad, tile[nl * stride + cl * taps + tap]);
   }
   if (ct == 0) {  // zero tail of each row: k in [taps*Cin, Kpad)
     const int k0 = taps * Cin, tail = Kpad - k0;
     for (int i = threadIdx.x; i < PACK_NT * tail; i += 256) {
       const int n = n0 + i / tail;
-      if (n < CoutPad) wf[(long)n * Kpad + k0 + i % tail] = from_f32<T>(0.f);
+      if (n < CoutPad) pack_store<T, X3>(wf, (long)n * Kpad + k0 + i % tail, (long)CoutPad * Kpad, 0.f);
     }
   }
   // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
@@ -736,13 +756,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
       const int nl = i % PACK_NT, tapf = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
       const int n = n0 + nl, c = c0 + cl;
       if (c < CinRows && n < CoutD)
-        wd[(long)c * KpadD + tapf * CoutD + n] = from_f32<T>(tile[nl * stride + cl * taps + (taps - 1 - tapf)]);
+        pack_store<T, X3>(wd, (long)c * KpadD + tapf * CoutD + n, (long)CinRows * KpadD,
+                          tile[nl * stride + cl * taps + (taps - 1 - tapf)]);
     }
     if (nt == 0) {
       const int k0 = taps * CoutD, tail = KpadD - k0;
       for (int i = threadIdx.x; i < CT * tail; i += 256) {
         const int c = c0 + i / tail;
-        if (c < CinRows) wd[(long)c * KpadD + k0 + i % tail] = from_f32<T>(0.f);
+        if (c < CinRows) pack_store<T, X3>(wd, (long)c * KpadD + k0 + i % tail, (long)CinRows * KpadD, 0.f);
       }
     }
   }
@@ -752,9 +773,11 @@ int pack_all_launch(int dtype, const float* params, void* ws, const PackTable& t
                     hipStream_t stream) {
   if (t.n == 0 || blocks == 0) return 0;
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(pack_all_kernel<float>, dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
+    hipLaunchKernelGGL((pack_all_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
+  else if (dtype == D3F_F32X3)
+    hipLaunchKernelGGL((pack_all_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
   else
-    hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
+    hipLaunchKernelGGL((pack_all_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, params, (char*)ws, t);
   D3F_HIP(hipGetLastError());
   return 0;
 }

@@ -12,11 +12,11 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, check, ptr, stream_ptr
 
-F32, BF16 = _lib.F32, _lib.BF16
+F32, BF16, F32X3 = _lib.F32, _lib.BF16, _lib.F32X3
 
 
 def _tdtype(dtype):
-    return torch.float32 if dtype == F32 else torch.bfloat16
+    return torch.bfloat16 if dtype == BF16 else torch.float32
 
 
 def _dev(t):

@@ -26,7 +26,8 @@ from . import _lib
 from ._lib import D3FError, check, ptr, stream_ptr
 
 _DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
-           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16}
+           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16,
+           "f32x3": _lib.F32X3}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -168,7 +169,7 @@ class Unet(nn.Module):
         if activation is not None:
             raise ValueError(f"Activation should be None (the reference passes activation=None); got {activation}")
         if compute_dtype not in _DTYPES:
-            raise ValueError(f"compute_dtype must be one of f32 / bf16, got {compute_dtype}")
+            raise ValueError(f"compute_dtype must be one of f32 / f32x3 / bf16, got {compute_dtype}")
         self.encoder_name, self.in_channels, self.classes = encoder_name, in_channels, classes
         self.compute_dtype = _DTYPES[compute_dtype]
         self.encoder = _Encoder(in_channels, _ENCODERS[encoder_name])

@@ -31,6 +31,10 @@ extern "C" {
 
 #define D3F_F32 0
 #define D3F_BF16 1
+/* fp32 tensors and fp32 accumulation; the contraction kernels split every fp32 operand exactly into three bf16
+ * terms and form each product from six bf16 MFMAs (dropped terms <= 2^-24 |a*b|): fp32-grade results at 6/16 of
+ * the fp32 MFMA time.  Everything that is not a contraction is identical to D3F_F32. */
+#define D3F_F32X3 2
 
 int d3f_version(void);
 const char* d3f_last_error(void);

@@ -22,7 +22,8 @@ def ops():
     return o
 
 
-def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=None, seed=0, splitk=False):
+def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=None, seed=0, splitk=False,
+               dtype=0):
     g = torch.Generator().manual_seed(seed)
     cin = C0 + C1
     cr = cin_real or cin
@@ -43,9 +44,9 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
     d = ops.make_desc(B, H, W, C0, C1, Cout, k, stride, pad, up, cr)
     s0 = to_nhwc(x0, C0).cuda()
     s1 = to_nhwc(x1).cuda() if x1 is not None else None
-    wf, wd = ops.pack_weights(d, w.cuda())
+    wf, wd = ops.pack_weights(d, w.cuda(), dtype)
     if Cout % 4 == 0:  # the 3-channel head runs through the NCHW epilogue of the whole-network path
-        y, stats, tiles = ops.conv_forward(d, s0, s1, wf, splitk=splitk)
+        y, stats, tiles = ops.conv_forward(d, s0, s1, wf, dtype, splitk=splitk)
         torch.cuda.synchronize()
         y_h = to_nchw(y.cpu())
         assert rel_l2(y_h, y_ref) < TOL_CONV, ("fwd", rel_l2(y_h, y_ref))
@@ -59,11 +60,11 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
     # weight gradient
     co_pad = (Cout + 3) // 4 * 4
     dy_h = to_nhwc(dy, co_pad).cuda()
-    dw = ops.conv_backward_weight(d, dy_h, s0, s1)
+    dw = ops.conv_backward_weight(d, dy_h, s0, s1, dtype)
     assert rel_l2(dw.cpu(), wr.grad) < TOL_CONV, ("wgrad", rel_l2(dw.cpu(), wr.grad))
     # data gradient (the padded first conv never needs one)
     if cin_real is None:
-        dx0, dx1 = ops.conv_backward_data(d, dy_h, wd, splitk=splitk)
+        dx0, dx1 = ops.conv_backward_data(d, dy_h, wd, dtype, splitk=splitk)
         dxr = xin.grad
         assert rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]) < TOL_CONV, ("dgrad0", rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]))
         if C1:
@@ -76,7 +77,7 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
             assert rel_l2(to_nchw(low.cpu()), x0r.grad) < 1e-6
         # accumulate flag
         base = torch.randn(dx0.shape, generator=g).cuda()
-        acc, _ = ops.conv_backward_data(d, dy_h, wd, dx0=base.clone(), dx1=dx1, acc0=True, splitk=splitk)
+        acc, _ = ops.conv_backward_data(d, dy_h, wd, dtype, dx0=base.clone(), dx1=dx1, acc0=True, splitk=splitk)
         assert rel_l2(acc.cpu(), (base + dx0).cpu()) < 1e-6
 
 
@@ -105,6 +106,20 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
 def test_conv_splitk_paths(ops, case):
     # same shapes with a workspace: the planner splits the K loop wherever M x Cout is small
     _conv_case(ops, *case, splitk=True)
+
+
+@pytest.mark.parametrize("splitk", [False, True])
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_f32x3(ops, case, splitk):
+    """D3F_F32X3: fp32 tensors, every product formed from six bf16 MFMAs over an exact 3-way split of both
+    operands.  Same tolerance as the fp32-MFMA path (the dropped terms are below fp32 rounding)."""
+    _conv_case(ops, *case, splitk=splitk, dtype=ops.F32X3)
+
+
+def test_conv_f32x3_first_layer_and_large_tiles(ops):
+    _conv_case(ops, 2, 32, 32, 4, 0, 64, 7, 2, 3, False, cin_real=3, dtype=ops.F32X3)
+    _conv_case(ops, 4, 128, 128, 32, 0, 128, 3, 1, 1, False, dtype=ops.F32X3)
+    _conv_case(ops, 4, 128, 128, 32, 0, 64, 3, 1, 1, False, seed=1, dtype=ops.F32X3)
 
 
 def test_conv_first_layer_7x7(ops):

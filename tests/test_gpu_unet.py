@@ -258,3 +258,43 @@ def test_poisoned_workspace(monkeypatch, dtype):
         g = torch.cat([p.grad.flatten().cpu() for p in net.parameters()])
         g_ref = torch.cat([p.grad.flatten() for p in ref.parameters()])
         assert rel_l2(g, g_ref) < CAP_GRAD_FLAT
+
+
+def test_f32x3_contraction_mode():
+    """compute_dtype="f32x3" (fp32 tensors; conv products from six bf16 MFMAs over an exact 3-way operand split)
+    meets the SAME gates as the fp32-MFMA path against the float64 oracle, forward and backward."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd import Unet
+    torch.manual_seed(2)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    x = oracle.synthetic_face_crops(4, 128, seed=3)
+    ref64 = copy.deepcopy(ref).double().train()
+    y64 = ref64(x.double())
+    y64.square().mean().backward()
+    g64 = torch.cat([p.grad.reshape(-1) for p in ref64.parameters()])
+    y_ref = ref(x)
+    y_ref.square().mean().backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    errs = {}
+    for dt in ("f32", "f32x3"):
+        net = Unet("resnet34", None, 3, 3, None, compute_dtype=dt)
+        net.load_state_dict(ref.state_dict())
+        net = net.cuda().train()
+        y = net(x.cuda())
+        y.square().mean().backward()
+        errs[dt] = (rel_l2(y, y64), rel_l2(net.flat_grads, g64))
+        for (n1, p1), (n3, p3) in zip(net.named_parameters(), ref64.named_parameters()):
+            assert rel_l2(p1.grad, p3.grad) < CAP_GRAD_TENSOR, (dt, n1)
+    e_cpu = (rel_l2(y_ref, y64), rel_l2(g_ref, g64))
+    print("rel-L2 vs float64 (forward, flat gradient): cpu-fp32 %.2e %.2e | f32 %.2e %.2e | f32x3 %.2e %.2e"
+          % (e_cpu + errs["f32"] + errs["f32x3"]))
+    for dt in errs:
+        assert _within(errs[dt][0], e_cpu[0], CAP_FWD, 2e-6), (dt, errs[dt], e_cpu)
+        assert _within(errs[dt][1], e_cpu[1], CAP_GRAD_FLAT, 2e-5, NOISE_GRAD), (dt, errs[dt], e_cpu)
+    # and the split mode is not measurably less accurate than the fp32 MFMA in the forward pass
+    assert errs["f32x3"][0] < 1.5 * errs["f32"][0] + 1e-7
