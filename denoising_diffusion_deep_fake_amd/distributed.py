@@ -40,13 +40,14 @@ def init_process_group(backend=None):
 class BucketAllReducer:
     """sum-all-reduce of gradient buckets, launched as they become ready, joined by wait()."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         self.group = group
         self.works = []
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force  # issue the collective even for one rank (exercises RCCL on a one-GPU box)
 
     def __call__(self, segment, flat_slice):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             self.works.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):

@@ -112,3 +112,53 @@ def test_data_parallel_two_ranks_one_gpu():
         assert o["scale"] == 0.5
         assert 0.009 < o["step"] <= 0.0101   # Adam's first step, averaged gradient
         assert o["in_sync"], "replicas must stay bit-identical after the step"
+
+
+def _rccl_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    torch.manual_seed(3)
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    opt = FusedAdam(net.parameters(), lr=0.01, betas=(0.5, 0.999), module=net)
+    x = synthetic_face_crops(2, 64, seed=9, device="cuda")
+
+    def grads(hook):
+        net.set_grad_sync(hook)
+        for p in net.parameters():
+            p.grad = None
+        pred = net(x)
+        _, g = ops.mse_ssim_loss(pred.detach(), x)
+        pred.backward(g)
+        if hook is not None:
+            hook.wait()
+        return net.flat_grads.clone()
+
+    plain = grads(None)
+    red = BucketAllReducer(force=True)
+    hooked = grads(red)
+    # a bucket broadcast as DataParallel does at attach time, and one optimizer step through before_step
+    dist.broadcast(net.flat_params, src=0)
+    opt.before_step = red.wait
+    opt.step()
+    torch.cuda.synchronize()
+    ret["equal"] = bool(torch.equal(plain, hooked))
+    ret["finite"] = bool(torch.isfinite(net.flat_params).all())
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank():
+    """the real RCCL backend ("nccl") on the one GPU: asynchronous bucket all-reduce launched from the
+    backward hook, joined by wait(); with one rank the sum is the identity, so gradients must be bit-identical
+    to the un-hooked pass (the 8-GPU run itself is the driver's)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_rccl_worker, (_free_port(), ret), 1, seconds=200)
+    assert ret.get("equal") is True and ret.get("finite") is True, dict(ret)
