@@ -806,7 +806,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //   CONV_RAW_STATS : out0[m][n] = sum (+ per-channel sum / sumsq partial per row block)
 //   CONV_DGRAD     : dual-destination store with optional accumulate
 // ---------------------------------------------------------------------------------------
-constexpr int SK_ROWS = 16;  // rows per reduce workgroup
+constexpr int SK_ROWS = 8;   // rows per reduce workgroup (small: the reduce is latency-bound, it wants many workgroups)
+constexpr int SK_MAX = 8;    // upper bound of splitk (plan)
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
@@ -822,11 +823,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
   for (int m = m_begin + r0; m < m_end; m += RP) {
     const long e = (long)m * p.Cout + cv * 4;
-    float4 v = *reinterpret_cast<const float4*>(p.partial + e);
-    for (int z = 1; z < p.splitk; ++z) {
-      const float4 w = *reinterpret_cast<const float4*>(p.partial + z * MN + e);
-      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-    }
+    // all slabs in flight at once (splitk is wave-uniform: scalar branches), summed in slab order
+    float4 w[SK_MAX];
+#pragma unroll
+    for (int z = 0; z < SK_MAX; ++z)
+      if (z < p.splitk) w[z] = *reinterpret_cast<const float4*>(p.partial + z * MN + e);
+    float4 v = w[0];
+#pragma unroll
+    for (int z = 1; z < SK_MAX; ++z)
+      if (z < p.splitk) { v.x += w[z].x; v.y += w[z].y; v.z += w[z].z; v.w += w[z].w; }
     float vv[4] = {v.x, v.y, v.z, v.w};
     if (p.mode == CONV_RAW_STATS) {
 #pragma unroll
@@ -947,9 +952,9 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
       (p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0)) {
     int sk = (int)((640 + base - 1) / base);
     while (sk > 1 && nk / sk < 6) --sk;  // keep >= 6 k-tiles per slice
-    if (sk > 8) sk = 8;
+    if (sk > SK_MAX) sk = SK_MAX;
     int fbm, fbn, fsk;
-    if (forced_tile(&fbm, &fbn, &fsk)) sk = fsk;
+    if (forced_tile(&fbm, &fbn, &fsk)) sk = fsk > SK_MAX ? SK_MAX : fsk;
     if (sk > 1) {
       p.splitk = sk;
       p.stat_rows = cdiv(p.M, SK_ROWS);
