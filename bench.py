@@ -32,11 +32,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame-size", type=int, default=448, help="--workload predict: frame height = width")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary f32x3 measurement of the default run")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the contraction kernels with HIP events in the timed region")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50"],
+    ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict"],
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
@@ -97,6 +98,50 @@ def extra_workload(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     torch.manual_seed(0)
+    if args.workload == "predict":
+        # single-frame inference: uint8 BGR frame -> uint8 BGR frame, B=1, at the
+        # authors' 448x448; device-resident frames (the PCIe-inclusive figure is reported next to it)
+        import numpy as np
+        from denoising_diffusion_deep_fake_amd import Unet
+        size = args.frame_size
+        net = Unet("resnet34", None, 3, 3, None, compute_dtype=args.dtype).to(dev).eval()
+        mean, std = [0.5] * 3, [0.5] * 3
+        mt, st = torch.tensor(mean, device=dev), torch.tensor(std, device=dev)
+        rng = np.random.default_rng(0)
+        host = rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)
+        fin = torch.from_numpy(host).to(dev)
+        fout = torch.empty((1, size, size, 3), dtype=torch.uint8, device=dev)
+
+        def unfused():
+            t = fin.flip(-1).float().permute(2, 0, 1)
+            t = ((t - mt.reshape(3, 1, 1) * 255) / (st.reshape(3, 1, 1) * 255)).unsqueeze(0).contiguous()
+            with torch.no_grad():
+                y = net(t)
+            y = (y.squeeze(0) * (st.reshape(3, 1, 1) * 255) + mt.reshape(3, 1, 1) * 255).permute(1, 2, 0)
+            return y.int().clamp(0, 255).to(torch.uint8).flip(-1)
+
+        def timed(fn, n):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+
+        def pcie():
+            fin.copy_(torch.from_numpy(host))
+            return net.predict_u8(fin, mean, std, graph=True, out=fout).cpu()
+        n = max(args.steps, 50)
+        res = {"workload": f"predict_fake single frame, B=1, {size}x{size}, uint8 BGR in/out", "dtype": args.dtype,
+               "ms_per_frame_unfused_torch_pre_post": round(timed(unfused, n), 4),
+               "ms_per_frame_fused_eager": round(timed(lambda: net.predict_u8(fin, mean, std, graph=False, out=fout), n), 4),
+               "ms_per_frame_fused_hipgraph": round(timed(lambda: net.predict_u8(fin, mean, std, graph=True, out=fout), n), 4),
+               "ms_per_frame_fused_hipgraph_pcie_inclusive": round(timed(pcie, n), 4)}
+        res["frames_per_sec"] = round(1e3 / min(res["ms_per_frame_fused_eager"], res["ms_per_frame_fused_hipgraph"]), 1)
+        print(json.dumps(res), flush=True)
+        return
     if args.workload == "deepfake":
         from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
         bs = 8

@@ -213,6 +213,12 @@ int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const fl
   D3F_CHECK(h && params && bnstats && x && out && workspace, "unet_forward: null argument");
   return h->e.forward(params, bnstats, x, out, workspace, training, (hipStream_t)stream);
 }
+int d3f_unet_predict_u8(d3f_unet_t h, const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                        const float mean[3], const float std[3], void* workspace, int use_graph, void* stream) {
+  D3F_CHECK(h && params && bnstats && bgr_in && bgr_out && mean && std && workspace, "predict_u8: null argument");
+  return h->e.predict_u8(params, bnstats, bgr_in, bgr_out, mean, std, workspace, use_graph, (hipStream_t)stream);
+}
+
 int d3f_unet_num_segments(d3f_unet_t h) { return h ? h->e.num_segments : -1; }
 int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end) {
   D3F_CHECK(h && segment >= 0 && segment < h->e.num_segments, "segment_range: segment %d", segment);

@@ -840,6 +840,16 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
         s2[k] += vv[k] * vv[k];
         o0[e + k] = from_f32<T>(vv[k]);
       }
+    } else if (p.mode == CONV_EVAL_FUSED) {  // folded BatchNorm (+ residual) (+ ReLU), as the fused epilogue
+      const int n = cv * 4;
+      const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = vv[k] * p.scale[n + k] + p.shift[n + k];
+        if (res != nullptr) x += to_f32<T>(res[e + k]);
+        if (p.relu) x = fmaxf(x, 0.f);
+        o0[e + k] = from_f32<T>(x);
+      }
     } else {  // CONV_DGRAD
       const int n = cv * 4;
       const bool first = n < p.out_c0;

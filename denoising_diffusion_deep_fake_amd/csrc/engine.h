@@ -77,6 +77,10 @@ class UnetEngine {
               hipStream_t s) const;
   int backward(const float* params, const float* dout, float* grads, void* ws, int seg_begin,
                int seg_end, hipStream_t s) const;
+  // eval-mode forward on uint8 BGR frames with the K16 pre/post kernels fused in (in_channels = classes = 3);
+  // use_graph: the launch sequence is captured once per set of pointers into a hipGraph and replayed
+  int predict_u8(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                 const float mean[3], const float stdv[3], void* ws, int use_graph, hipStream_t s) const;
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
 
   std::vector<ParamInfo> params;
@@ -114,6 +118,16 @@ class UnetEngine {
   static constexpr int NDY = 4;  // dY buffers: how far the side stream may lag behind the main chain
   mutable hipEvent_t ev_dy_[NDY] = {}, ev_wg_[NDY] = {}, ev_join_ = nullptr;
   mutable bool wg_pending_[NDY] = {};
+  // predict_u8 graph: private capture/launch stream + the pointers and constants the captured graph bakes in
+  int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
+  int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                          const float mean255[3], const float std255[3], char* ws, hipStream_t s) const;
+  mutable hipStream_t gstream_ = nullptr;
+  mutable hipGraphExec_t gexec_ = nullptr;
+  mutable hipEvent_t ev_gin_ = nullptr, ev_gout_ = nullptr;
+  mutable const void* gkey_[5] = {};
+  mutable float gconst_[6] = {};
+  size_t head_nchw_off = 0;
   size_t dyn_off[NDY] = {};
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;

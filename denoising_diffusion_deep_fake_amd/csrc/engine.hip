@@ -359,6 +359,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   wpart_off = alloc(wpart_bytes);
   bsum_off = alloc((size_t)classes * CS_PARTS * sizeof(float));
   splitk_off = alloc(splitk_bytes);
+  head_nchw_off = alloc((size_t)B * classes * H * W * sizeof(float));  // predict_u8: head output before K16 post
   workspace_bytes = ws_top;
 
   // ---- gradient buckets (contiguous slices of the flat gradient, ready in this order) ----
@@ -433,15 +434,28 @@ static inline float* coef_ptr(char* ws, const Unit& u, int which) {
 int UnetEngine::forward(const float* params_, float* bnstats, const float* x, float* out, void* ws_,
                         int training, hipStream_t s) const {
   char* ws = reinterpret_cast<char*>(ws_);
+  if (int rc = nchw_to_nhwc_launch(dtype, x, ws + tensors[t_x].off, B, in_channels, H, W, tensors[t_x].C, s))
+    return rc;
+  return forward_body(params_, bnstats, out, ws, training, s);
+}
+
+// everything after the input layout conversion; `out` = NCHW fp32 destination of the head
+int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, char* ws, int training,
+                             hipStream_t s) const {
   auto T = [&](int tid) { return ws + tensors[tid].off; };
-  if (int rc = nchw_to_nhwc_launch(dtype, x, T(t_x), B, in_channels, H, W, tensors[t_x].C, s)) return rc;
-  if (!training) {
+  if (!training) {  // folded BatchNorm coefficients of all layers: one launch
+    BnEvalTable t;
+    t.n = 0;
     for (const Unit& u : units)
-      if (u.bn)
-        if (int rc = bn_eval_coeff_launch(params_ + u.g_off, params_ + u.b_off, bnstats + u.rm_off,
-                                          bnstats + u.rv_off, 1e-5f, u.Cout, coef_ptr(ws, u, 2),
-                                          coef_ptr(ws, u, 3), s))
-          return rc;
+      if (u.bn) {
+        D3F_CHECK(t.n < PACK_MAX_LAYERS && u.coef_off % 16 == 0, "eval coefficients: table overflow");
+        BnEvalEntry& e = t.e[t.n++];
+        e.g_off = (uint32_t)u.g_off; e.b_off = (uint32_t)u.b_off;
+        e.rm_off = (uint32_t)u.rm_off; e.rv_off = (uint32_t)u.rv_off;
+        e.coef_off16 = (uint32_t)(u.coef_off >> 4);
+        e.C = u.Cout;
+      }
+    if (int rc = bn_eval_coeff_all_launch(params_, bnstats, ws, 1e-5f, t, s)) return rc;
   }
   for (int ui : fwd_order_) {
     if (ui < 0) {
@@ -489,6 +503,7 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
       p.scale = coef_ptr(ws, u, 2);
       p.shift = coef_ptr(ws, u, 3);
       p.relu = u.relu ? 1 : 0;
+      p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;  // small batches: split K
       if (u.apply) {
         p.out0 = T(u.a);
         p.res = u.res_tensor >= 0 ? T(u.res_tensor) : (ds ? T(ds->y) : nullptr);
@@ -502,7 +517,71 @@ int UnetEngine::forward(const float* params_, float* bnstats, const float* x, fl
   return 0;
 }
 
+int UnetEngine::predict_u8_launches(const float* params_, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                                    const float mean255[3], const float std255[3], char* ws, hipStream_t s) const {
+  if (int rc = u8bgr_to_nhwc_launch(dtype, bgr_in, ws + tensors[t_x].off, (long)B * H * W, tensors[t_x].C, mean255,
+                                    std255, s))
+    return rc;
+  float* head_out = reinterpret_cast<float*>(ws + head_nchw_off);
+  if (int rc = forward_body(params_, bnstats, head_out, ws, 0, s)) return rc;
+  return nchw_to_u8bgr_launch(head_out, bgr_out, B, (long)H * W, mean255, std255, s);
+}
+
+int UnetEngine::predict_u8(const float* params_, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                           const float mean[3], const float stdv[3], void* ws_, int use_graph,
+                           hipStream_t s) const {
+  D3F_CHECK(in_channels == 3 && classes == 3, "predict_u8: 3-channel frames only (in %d, out %d)", in_channels, classes);
+  char* ws = reinterpret_cast<char*>(ws_);
+  float m255[3], s255[3];
+  for (int c = 0; c < 3; ++c) {  // fp32 products, as torch.tensor(mean) * 255 gives
+    m255[c] = mean[c] * 255.0f;
+    s255[c] = stdv[c] * 255.0f;
+  }
+  if (!use_graph) return predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, s);
+
+  // hipGraph path: at B = 1 the ~100 launches of an eval forward are launch-bound; capture them once
+  if (gstream_ == nullptr) {
+    D3F_HIP(hipStreamCreateWithFlags(&gstream_, hipStreamNonBlocking));
+    D3F_HIP(hipEventCreateWithFlags(&ev_gin_, hipEventDisableTiming));
+    D3F_HIP(hipEventCreateWithFlags(&ev_gout_, hipEventDisableTiming));
+  }
+  const void* key[5] = {params_, bnstats, bgr_in, bgr_out, ws_};
+  const float cst[6] = {m255[0], m255[1], m255[2], s255[0], s255[1], s255[2]};
+  const bool same = gexec_ != nullptr && memcmp(key, gkey_, sizeof(key)) == 0 && memcmp(cst, gconst_, sizeof(cst)) == 0;
+  if (!same) {
+    if (gexec_) {
+      (void)hipGraphExecDestroy(gexec_);
+      gexec_ = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    D3F_HIP(hipStreamBeginCapture(gstream_, hipStreamCaptureModeThreadLocal));
+    const int rc = predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, gstream_);
+    const hipError_t e = hipStreamEndCapture(gstream_, &graph);
+    if (rc != 0) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    D3F_HIP(e);
+    const hipError_t ei = hipGraphInstantiate(&gexec_, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    D3F_HIP(ei);
+    memcpy(gkey_, key, sizeof(key));
+    memcpy(gconst_, cst, sizeof(cst));
+  }
+  // order the replay after the caller's stream (input frame, packed weights) and the caller after the replay
+  D3F_HIP(hipEventRecord(ev_gin_, s));
+  D3F_HIP(hipStreamWaitEvent(gstream_, ev_gin_, 0));
+  D3F_HIP(hipGraphLaunch(gexec_, gstream_));
+  D3F_HIP(hipEventRecord(ev_gout_, gstream_));
+  D3F_HIP(hipStreamWaitEvent(s, ev_gout_, 0));
+  return 0;
+}
+
 UnetEngine::~UnetEngine() {
+  if (gexec_) (void)hipGraphExecDestroy(gexec_);
+  if (ev_gin_) (void)hipEventDestroy(ev_gin_);
+  if (ev_gout_) (void)hipEventDestroy(ev_gout_);
+  if (gstream_) (void)hipStreamDestroy(gstream_);
   for (int i = 0; i < NDY; ++i) {
     if (ev_dy_[i]) (void)hipEventDestroy(ev_dy_[i]);
     if (ev_wg_[i]) (void)hipEventDestroy(ev_wg_[i]);

@@ -4,6 +4,8 @@
 
 namespace d3f {
 
+constexpr int PACK_MAX_LAYERS = 64;  // layers per kernel-argument table
+
 // ---- BatchNorm, train mode (K5/K7) ------------------------------------------------------
 // stats: per-m-tile partial (sum, sumsq) written by the conv epilogue.
 // Produces mean / invstd (saved for backward), folded scale / shift, and updates the
@@ -16,6 +18,18 @@ int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long coun
 int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift,
                          hipStream_t stream);
+// the same for every BatchNorm of a network in one launch: scale -> coef[2*C..], shift -> coef[3*C..]
+struct BnEvalEntry {
+  uint32_t g_off, b_off, rm_off, rv_off;  // floats into params / bnstats
+  uint32_t coef_off16;                     // 16-byte units into the workspace
+  int32_t C;
+};
+struct BnEvalTable {
+  int n;
+  BnEvalEntry e[PACK_MAX_LAYERS];
+};
+int bn_eval_coeff_all_launch(const float* params, const float* bnstats, void* ws, float eps, const BnEvalTable& t,
+                             hipStream_t stream);
 // a = act(y*scale + shift + residual),  residual = res (activation) or yr*scale_r + shift_r
 int bn_apply_launch(int dtype, const void* y, const float* scale, const float* shift,
                     const void* res, const void* yr, const float* scale_r, const float* shift_r,
@@ -49,6 +63,12 @@ int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int
 int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad,
                         hipStream_t stream);
 
+// K16: uint8 BGR frames <-> normalised activations (mean255 = mean*255, std255 = std*255, RGB order)
+int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int Cpad, const float mean255[3],
+                         const float std255[3], hipStream_t stream);
+int nchw_to_u8bgr_launch(const float* in, uint8_t* out, int B, long HW, const float mean255[3],
+                         const float std255[3], hipStream_t stream);
+
 // ---- weights -------------------------------------------------------------------------------
 // PyTorch [Cout][CinReal][KH][KW] fp32 -> forward pack [CoutPad][Kpad] (k = tap*Cin + c) and/or
 // data-gradient pack [CinPadRows][KpadD] (k = flipped tap*Cout + co); T = dtype.
@@ -57,7 +77,6 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
                         hipStream_t stream);
 
 // every layer of a network in one launch (engine): table passed by value as a kernel argument
-constexpr int PACK_MAX_LAYERS = 64;
 constexpr int PACK_NT = 32;        // filters per tile
 constexpr int PACK_LDS_ROW = 288;  // floats per filter in a tile: CT channels x taps  (32 x 9)
 struct PackEntry {

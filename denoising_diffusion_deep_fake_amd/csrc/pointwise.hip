@@ -123,6 +123,28 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// every BatchNorm of the network in one launch (eval forward): block = layer, table as kernel argument
+__global__ __launch_bounds__(256) void bn_eval_coeff_all_kernel(const float* __restrict__ params,
+                                                                const float* __restrict__ bnstats,
+                                                                char* __restrict__ ws, float eps, BnEvalTable t) {
+  const BnEvalEntry e = t.e[blockIdx.x];
+  float* __restrict__ coef = reinterpret_cast<float*>(ws + (size_t)e.coef_off16 * 16);
+  for (int c = threadIdx.x; c < e.C; c += 256) {
+    const float invstd = 1.0f / sqrtf(bnstats[e.rv_off + c] + eps);
+    const float sc = params[e.g_off + c] * invstd;
+    coef[2 * e.C + c] = sc;
+    coef[3 * e.C + c] = params[e.b_off + c] - bnstats[e.rm_off + c] * sc;
+  }
+}
+
+int bn_eval_coeff_all_launch(const float* params, const float* bnstats, void* ws, float eps, const BnEvalTable& t,
+                             hipStream_t stream) {
+  if (t.n == 0) return 0;
+  hipLaunchKernelGGL(bn_eval_coeff_all_kernel, dim3(t.n), dim3(256), 0, stream, params, bnstats, (char*)ws, eps, t);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
 int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift,
                          hipStream_t stream) {
@@ -606,6 +628,66 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     const long b = i / HW, pix = i - b * HW;
     for (int c = 0; c < C; ++c) out[(b * C + c) * HW + pix] = to_f32<T>(in[i * Cpad + c]);
   }
+}
+
+// K16 (inference boundary, d3f/train_deep_fake/lit_module.py:272-300): uint8 BGR frames [B][H][W][3] ->
+// normalised NHWC activations in RGB order, (float(u8) - mean*255) / (std*255) in the reference's order of
+// fp32 operations; and the way back: y*std*255 + mean*255, .int() truncation, clamp(0, 255), RGB -> BGR.
+template <typename T>
+__global__ __launch_bounds__(256) void u8bgr_to_nhwc_kernel(const uint8_t* __restrict__ in, T* __restrict__ out,
+                                                            long npix, int Cpad, float m0, float m1, float m2,
+                                                            float s0, float s1, float s2) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const uint8_t* px = in + i * 3;
+    const float r = ((float)px[2] - m0) / s0, g = ((float)px[1] - m1) / s1, b = ((float)px[0] - m2) / s2;
+    T* o = out + i * Cpad;
+    o[0] = from_f32<T>(r);
+    o[1] = from_f32<T>(g);
+    o[2] = from_f32<T>(b);
+    for (int c = 3; c < Cpad; ++c) o[c] = from_f32<T>(0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_u8bgr_kernel(const float* __restrict__ in, uint8_t* __restrict__ out,
+                                                            int B, long HW, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, pix = i - b * HW;
+    const float* src = in + b * 3 * HW + pix;
+    auto q = [](float y, float s, float m) {
+      const float v = y * s + m;      // two roundings, like the reference's in-place mul then add
+      int t = (int)v;                 // .int(): truncation toward zero
+      t = t < 0 ? 0 : (t > 255 ? 255 : t);
+      return (uint8_t)t;
+    };
+    uint8_t* o = out + i * 3;
+    o[2] = q(src[0], s0, m0);
+    o[1] = q(src[HW], s1, m1);
+    o[0] = q(src[2 * HW], s2, m2);
+  }
+}
+
+int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int Cpad, const float mean255[3],
+                         const float std255[3], hipStream_t stream) {
+  if (npix == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(u8bgr_to_nhwc_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, stream, in, (float*)out, npix,
+                       Cpad, mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2]);
+  else
+    hipLaunchKernelGGL(u8bgr_to_nhwc_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, stream, in, (bf16_t*)out,
+                       npix, Cpad, mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2]);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int nchw_to_u8bgr_launch(const float* in, uint8_t* out, int B, long HW, const float mean255[3],
+                         const float std255[3], hipStream_t stream) {
+  if ((long)B * HW == 0) return 0;
+  hipLaunchKernelGGL(nchw_to_u8bgr_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, stream, in, out, B, HW,
+                     mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2]);
+  D3F_HIP(hipGetLastError());
+  return 0;
 }
 
 int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad,

@@ -393,6 +393,40 @@ class Unet(nn.Module):
             return _UnetFunction.apply(xin, self, eng, *params)
         return self._run_forward(eng, xin, training=self.training)
 
+    @torch.no_grad()
+    def predict_u8(self, frames_bgr, mean, std, graph=True, out=None):
+        """Inference on uint8 BGR frames ([H,W,3] or [B,H,W,3] on the HIP device) -> uint8 BGR frames.
+
+        Eval-mode forward (BatchNorm running statistics folded into the conv epilogues) with the reference's
+        `cv2_to_tensor_normalised` / `tensor_cv2_to_denormalised` (d3f/train_deep_fake/lit_module.py:272-300) fused
+        into the first and last kernel; `graph=True` replays a hipGraph captured per (input, output) buffer pair,
+        so pass the same buffers again (`out=`) in a frame loop."""
+        if frames_bgr.dtype != torch.uint8 or frames_bgr.shape[-1] != 3 or frames_bgr.dim() not in (3, 4):
+            raise ValueError("predict_u8 expects uint8 frames [H, W, 3] or [B, H, W, 3] in BGR order")
+        if frames_bgr.device.type != "cuda":
+            raise D3FError("predict_u8 needs frames on the HIP device (no CPU fallback)")
+        single = frames_bgr.dim() == 3
+        x = frames_bgr.unsqueeze(0) if single else frames_bgr
+        x = x.contiguous()
+        B, H, W, _ = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"Wrong input shape height={H}, width={W}. Expected image height and width "
+                               f"divisible by 32.")
+        self._ensure_flat(x.device)
+        eng = self._engine(B, H, W, x.device)
+        self._pack_if_needed(eng)
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.shape != x.shape or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor shaped like the input batch")
+        rt = self._rt
+        m = (C.c_float * 3)(*[float(v) for v in mean])
+        sd = (C.c_float * 3)(*[float(v) for v in std])
+        check(_lib.lib().d3f_unet_predict_u8(eng.h, ptr(rt["flat"]), ptr(rt["flat_bn"]), ptr(x), ptr(out), m, sd,
+                                             ptr(eng.workspace), 1 if graph else 0, stream_ptr()))
+        eng.keep = (x, out)  # the captured graph bakes these pointers in: keep them alive with the engine
+        return out[0] if single else out
+
     # flops of the conv contractions of one call (2*MAC), for roofline reporting
     def conv_flops(self, B, H, W, device=None):
         device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())

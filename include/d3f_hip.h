@@ -87,6 +87,14 @@ int d3f_unet_pack_weights(d3f_unet_t h, const float* params, void* workspace, vo
  * updates bnstats (momentum 0.1) and keeps what backward needs in the workspace. */
 int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
                      void* workspace, int training, void* stream);
+/* Inference entry behind LitModule.predict_fake_for_single_frame (d3f/train_deep_fake/lit_module.py:259-300):
+ * uint8 BGR frames [B][H][W][3] in device memory -> eval-mode forward (BatchNorm folded into the conv
+ * epilogues) -> uint8 BGR frames, with cv2_to_tensor_normalised (:272-283: BGR->RGB, (x - mean*255) / (std*255))
+ * and tensor_cv2_to_denormalised (:285-300: x*std*255 + mean*255, .int() truncation, clamp 0..255, RGB->BGR)
+ * fused into the first and last kernel.  mean / std: 3 host floats (RGB order).  use_graph != 0: the launch
+ * sequence is captured into a hipGraph on first use (per set of pointers) and replayed afterwards. */
+int d3f_unet_predict_u8(d3f_unet_t h, const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
+                        const float mean[3], const float std[3], void* workspace, int use_graph, void* stream);
 /* gradients of every parameter (written, not accumulated) for the preceding training forward.
  * The backward pass is cut into d3f_unet_num_segments() buckets so a data-parallel caller can
  * all-reduce bucket k while bucket k+1 computes: run segments [seg_begin, seg_end) in order 0..n;

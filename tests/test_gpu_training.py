@@ -157,6 +157,55 @@ def test_predict_fake_matches_oracle():
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01  # .int() truncation flips on float-noise ties only
 
 
+def test_predict_u8_fused_and_graph_paths_are_bit_exact():
+    """K16 + hipGraph: the fused uint8 path, eager and graph-replayed, must give exactly the
+    bytes of the unfused reference sequence (cv2_to_tensor_normalised -> eval forward -> tensor_cv2_to_denormalised)
+    on the same device arithmetic; frames, weights and batch size change between replays."""
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    torch.manual_seed(6)
+    lit = LitModule(**HP_FAKE).cuda().eval()
+    net = lit.model_a
+    with torch.no_grad():  # non-trivial running statistics
+        for name, buf in net.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0, 0.1)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    net.mark_params_changed()
+    mean, std = [0.4, 0.5, 0.6], [0.5, 0.45, 0.55]
+    mt, st = torch.tensor(mean, device="cuda"), torch.tensor(std, device="cuda")
+    rng = np.random.default_rng(1)
+
+    def unfused(frame):
+        with torch.no_grad():
+            return lit.tensor_cv2_to_denormalised(net(lit.cv2_to_tensor_normalised(frame, mt, st)), mt, st)
+
+    buf_in = torch.empty((64, 96, 3), dtype=torch.uint8, device="cuda")
+    buf_out = torch.empty((1, 64, 96, 3), dtype=torch.uint8, device="cuda")
+    for it in range(4):
+        frame = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+        want = unfused(frame)
+        buf_in.copy_(torch.from_numpy(frame))
+        eager = net.predict_u8(buf_in, mean, std, graph=False).cpu().numpy()
+        replay = net.predict_u8(buf_in, mean, std, graph=True, out=buf_out).cpu().numpy()
+        assert np.array_equal(eager, want), (it, np.abs(eager.astype(int) - want.astype(int)).max())
+        assert np.array_equal(replay, want), it
+        if it == 1:  # a parameter update between replays: the graph must see the re-packed weights
+            with torch.no_grad():
+                net.segmentation_head[0].bias.add_(0.05)
+                next(iter(net.parameters())).mul_(1.01)
+    # the LitModule entry (host frame in, host frame out) and a batch of frames
+    frame = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    lit.hparams.mean_b, lit.hparams.std_b = mean, std
+    assert np.array_equal(lit.predict_fake(frame, "a"), unfused(frame))
+    batch = torch.from_numpy(rng.integers(0, 256, size=(3, 32, 64, 3), dtype=np.uint8)).cuda()
+    got = net.predict_u8(batch, mean, std).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], unfused(batch[i].cpu().numpy()))
+    with pytest.raises(RuntimeError):
+        net.predict_u8(torch.zeros((30, 64, 3), dtype=torch.uint8, device="cuda"), mean, std)
+
+
 def test_trainer_fit_checkpoint_resume(tmp_path):
     from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
     from denoising_diffusion_deep_fake_amd.trainer import Trainer
