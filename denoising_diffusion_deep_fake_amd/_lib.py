@@ -47,6 +47,7 @@ PROTOTYPES = {
     "d3f_unet_backward_flops": (_dbl, [_p]),
     "d3f_unet_pack_weights": (_i, [_p, _p, _p, _p]),
     "d3f_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    "d3f_affine_warp": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "d3f_unet_predict_u8": (_i, [_p, _p, _p, _p, _p, C.POINTER(_f), C.POINTER(_f), _p, _i, _p]),
     "d3f_unet_num_segments": (_i, [_p]),
     "d3f_unet_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),

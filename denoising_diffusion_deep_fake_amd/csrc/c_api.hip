@@ -356,6 +356,12 @@ int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int
   D3F_CHECK(dfull && dlow, "upsample2x_backward: null argument");
   return sum2x2_launch(sdt(dtype), dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
 }
+int d3f_affine_warp(const float* in, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
+  D3F_CHECK(in && theta && out && in != out, "affine_warp: null or aliased argument");
+  D3F_CHECK(B >= 0 && C > 0 && H > 0 && W > 0, "affine_warp: bad shape");
+  return affine_warp_launch(in, theta, out, B, C, H, W, (hipStream_t)stream);
+}
+
 int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream) {
   D3F_CHECK(in && out && Cpad >= C, "nchw_to_nhwc: argument");
   return nchw_to_nhwc_launch(sdt(dtype), in, out, B, C, H, W, Cpad, (hipStream_t)stream);

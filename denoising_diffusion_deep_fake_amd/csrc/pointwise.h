@@ -69,6 +69,10 @@ int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int
 int nchw_to_u8bgr_launch(const float* in, uint8_t* out, int B, long HW, const float mean255[3],
                          const float std255[3], hipStream_t stream);
 
+// K17: affine_grid + grid_sample(bilinear, zeros, align_corners=False) on NCHW fp32, theta [B][2][3]
+int affine_warp_launch(const float* in, const float* theta, float* out, int B, int C, int H, int W,
+                       hipStream_t stream);
+
 // ---- weights -------------------------------------------------------------------------------
 // PyTorch [Cout][CinReal][KH][KW] fp32 -> forward pack [CoutPad][Kpad] (k = tap*Cin + c) and/or
 // data-gradient pack [CinPadRows][KpadD] (k = flipped tap*Cout + co); T = dtype.

@@ -668,6 +668,48 @@ __global__ __launch_bounds__(256) void nchw_to_u8bgr_kernel(const float* __restr
   }
 }
 
+// K17: batched affine warp of NCHW fp32 images -- affine_grid + grid_sample(bilinear, zeros, align_corners=False)
+// in one pass (the GPU-side augmentation of train_denoiser, d3f/train_denoiser/lit_module.py:55-65,113).
+// theta [B][2][3] maps normalised output coordinates to normalised input coordinates.
+__global__ __launch_bounds__(256) void affine_warp_kernel(const float* __restrict__ in, const float* __restrict__ theta,
+                                                          float* __restrict__ out, int B, int C, int H, int W) {
+  const long HW = (long)H * W, total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / HW);
+    const int pix = (int)(i - (long)b * HW);
+    const int y = pix / W, x = pix - y * W;
+    const float* t = theta + b * 6;
+    const float xn = (2.0f * x + 1.0f) / W - 1.0f, yn = (2.0f * y + 1.0f) / H - 1.0f;
+    const float xs = t[0] * xn + t[1] * yn + t[2], ys = t[3] * xn + t[4] * yn + t[5];
+    const float fx = ((xs + 1.0f) * W - 1.0f) * 0.5f, fy = ((ys + 1.0f) * H - 1.0f) * 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = fx - x0f, wy1 = fy - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const float* src = in + (long)b * C * HW;
+    float* dst = out + (long)b * C * HW + pix;
+    for (int c = 0; c < C; ++c) {
+      const float* pl = src + (long)c * HW;
+      const float v00 = (vx0 && vy0) ? pl[(long)y0 * W + x0] : 0.f;
+      const float v01 = (vx1 && vy0) ? pl[(long)y0 * W + x0 + 1] : 0.f;
+      const float v10 = (vx0 && vy1) ? pl[(long)(y0 + 1) * W + x0] : 0.f;
+      const float v11 = (vx1 && vy1) ? pl[(long)(y0 + 1) * W + x0 + 1] : 0.f;
+      dst[(long)c * HW] = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+    }
+  }
+}
+
+int affine_warp_launch(const float* in, const float* theta, float* out, int B, int C, int H, int W,
+                       hipStream_t stream) {
+  const long total = (long)B * H * W;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(affine_warp_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, in, theta, out, B, C,
+                     H, W);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
 int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int Cpad, const float mean255[3],
                          const float std255[3], hipStream_t stream) {
   if (npix == 0) return 0;

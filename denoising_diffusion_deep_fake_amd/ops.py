@@ -151,6 +151,18 @@ def upsample2x_backward(dfull, dtype=F32):
     return out
 
 
+def affine_warp(x, theta):
+    """affine_grid + grid_sample(bilinear, zeros, align_corners=False) of NCHW f32 images, theta [B, 2, 3]."""
+    x = x.contiguous().float()
+    B, Cc, H, W = x.shape
+    theta = theta.to(device=_dev(x), dtype=torch.float32).contiguous()
+    if theta.shape != (B, 2, 3):
+        raise ValueError(f"theta must be [{B}, 2, 3], got {list(theta.shape)}")
+    out = torch.empty_like(x)
+    check(_lib.lib().d3f_affine_warp(ptr(x), ptr(theta), ptr(out), B, Cc, H, W, stream_ptr()))
+    return out
+
+
 def noise_blend(x, noise, y_uniform, lam, return_r=False):
     x = x.contiguous().float()
     out = torch.empty_like(x)

@@ -8,9 +8,9 @@ Differences, all outside the parity-checked arithmetic
   * the reference's dataloader transform is bit-rotted (nn.Sequential(T.Normalize) called with
     image=...); this module uses the train_deep_fake convention (Normalize + ToTensor) so the
     command actually runs; `synthetic: true` swaps in the synthetic face-crop dataset;
-  * kornia's RandomAffine is replaced by a torch affine_grid/grid_sample stand-in with the same
-    parameter ranges (augmentation is random, not part of the numerics contract), off by default
-    in benchmarks (`augment: false`).
+  * kornia's RandomAffine is replaced by the same parameter ranges drawn with torch RNG and one HIP warp
+    kernel (ops.affine_warp = affine_grid + grid_sample(bilinear, zeros), parity-tested against torch on CPU);
+    the random draws themselves are not part of the numerics contract; off in benchmarks (`augment: false`).
 """
 import math
 
@@ -44,8 +44,7 @@ class RandomAffine(torch.nn.Module):
         ty = (torch.rand(B, device=dev) * 2 - 1) * self.translate[1] * 2
         cos, sin = torch.cos(ang) / sc, torch.sin(ang) / sc
         theta = torch.stack([torch.stack([cos, -sin, tx], 1), torch.stack([sin, cos, ty], 1)], 1)
-        grid = F.affine_grid(theta, list(x.shape), align_corners=False)
-        return F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+        return ops.affine_warp(x, theta)  # K17: affine_grid + grid_sample(bilinear, zeros) in one HIP kernel
 
 
 class LitModule(LightningModule):

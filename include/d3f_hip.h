@@ -160,6 +160,10 @@ int d3f_maxpool3x3s2_backward(int dtype, const void* dout, const uint8_t* idx, v
 int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int Hlow, int Wlow, int C, void* stream);
 int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream);
 int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad, void* stream);
+/* GPU-side augmentation of the training step (d3f/train_denoiser/lit_module.py:55-65 RandomAffine, applied at :113):
+ * out[b] = grid_sample(in[b], affine_grid(theta[b]), bilinear, zeros padding, align_corners=False), NCHW f32,
+ * theta [B][2][3] row-major (normalised output -> input coordinates).  in and out must not alias. */
+int d3f_affine_warp(const float* in, const float* theta, float* out, int B, int C, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training-step arithmetic around the network

@@ -269,6 +269,34 @@ def test_adam_and_ema(ops):
         torch.testing.assert_close(e.cpu(), torch.lerp(a, b, w), rtol=1e-6, atol=1e-7)
 
 
+def test_affine_warp_matches_torch_grid_sample(ops):
+    """K17 against F.grid_sample(F.affine_grid(theta), bilinear, zeros, align_corners=False) on CPU.  Tolerance:
+    the sampling coordinates are computed in a different order of fp32 operations (1-2 ulp of a coordinate up to
+    W ~ 1e-4 pixel), so interpolation weights differ by ~1e-4 * |neighbour difference|: rel-L2 <= 2e-5 on smooth
+    face-like crops, max abs 2e-4 on white noise in [-1, 1]."""
+    import math
+    import oracle
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 5, 64, 96
+    ang = (torch.rand(B, generator=g) * 2 - 1) * math.radians(15)
+    sc = torch.rand(B, generator=g) * 0.4 + 0.8
+    tx, ty = (torch.rand(B, generator=g) * 2 - 1) * 0.4, (torch.rand(B, generator=g) * 2 - 1) * 0.4
+    cos, sin = torch.cos(ang) / sc, torch.sin(ang) / sc
+    theta = torch.stack([torch.stack([cos, -sin, tx], 1), torch.stack([sin, cos, ty], 1)], 1)
+    theta[0] = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])      # identity
+    theta[1] = torch.tensor([[0.5, 0.0, 1.2], [0.0, 0.5, -1.1]])     # mostly outside the image: zero border
+    for x in (oracle.synthetic_face_crops(B, 64, seed=2)[:, :, :, :64].repeat(1, 1, 1, 2)[:, :, :H, :W].contiguous(),
+              torch.rand(B, 3, H, W, generator=g) * 2 - 1):
+        want = F.grid_sample(x, F.affine_grid(theta, list(x.shape), align_corners=False), mode="bilinear",
+                             padding_mode="zeros", align_corners=False)
+        got = ops.affine_warp(x.cuda(), theta.cuda()).cpu()
+        assert rel_l2(got, want) < 2e-5 or (got - want).abs().max() < 2e-4, (rel_l2(got, want), (got - want).abs().max())
+        assert (got - want).abs().max() < 2e-4
+        assert (got[0] - x[0]).abs().max() < 1e-5   # identity
+    with pytest.raises(ValueError):
+        ops.affine_warp(x.cuda(), theta[:2].cuda())
+
+
 def test_layout_roundtrip(ops):
     x = torch.randn(2, 3, 8, 10)
     h = ops.nchw_to_nhwc(x.cuda(), 4)
