@@ -378,6 +378,17 @@ int d3f_noise_blend(const float* x, const float* noise, const float* y_uniform, 
   return noise_blend_launch(x, noise, y_uniform, lam, out, r_out_or_null, B, (long)per_image,
                             (hipStream_t)stream);
 }
+int d3f_noise_blend_fixed(const float* x, const float* noise, const float* r, float* out, int B, int64_t per_image,
+                          void* stream) {
+  D3F_CHECK(x && noise && r && out, "noise_blend_fixed: null argument");
+  return noise_blend_fixed_launch(x, noise, r, out, B, (long)per_image, (hipStream_t)stream);
+}
+size_t d3f_l1_per_image_workspace_bytes(int B) { return l1_per_image_workspace_bytes(B); }
+int d3f_l1_per_image(const float* prediction, const float* target, float* out, void* workspace, int B,
+                     int64_t per_image, void* stream) {
+  D3F_CHECK(prediction && target && out && workspace, "l1_per_image: null argument");
+  return l1_per_image_launch(prediction, target, out, workspace, B, (long)per_image, (hipStream_t)stream);
+}
 size_t d3f_mse_ssim_loss_workspace_bytes(int B, int H, int W) {
   return loss_workspace_floats(B, H, W) * sizeof(float);
 }

@@ -290,8 +290,10 @@ __global__ __launch_bounds__(256) void noise_blend_kernel(const float* __restric
   const float t = __fadd_rn(__fmul_rn(y_uniform[b], one_minus_c), c);
   // log / sqrt evaluated in double and rounded once: correctly rounded f32 results (the device's
   // f32 logf / sqrtf are 1-2 ulp off the host libm the reference's CPU path uses); 3 ops per image
-  const float r = __fmul_rn(inv_lam, (float)log((double)__fdiv_rn(1.0f, t)));
-  const float sa = (float)sqrt((double)__fsub_rn(1.0f, r)), sb = (float)sqrt((double)r);
+  // inv_lam <= 0: fixed-ratio mode (balance_training_images), y_uniform holds r itself
+  const float r = inv_lam > 0.f ? __fmul_rn(inv_lam, (float)log((double)__fdiv_rn(1.0f, t))) : y_uniform[b];
+  // __fsqrt_rn: IEEE correctly rounded f32 square root
+  const float sa = __fsqrt_rn(__fsub_rn(1.0f, r)), sb = __fsqrt_rn(r);
   if (r_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) r_out[b] = r;
   const long nvec = per_image / 4;
   const float4* __restrict__ xv = reinterpret_cast<const float4*>(x + (long)b * per_image);
@@ -319,6 +321,58 @@ int noise_blend_launch(const float* x, const float* noise, const float* y_unifor
   hipLaunchKernelGGL(noise_blend_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, x, noise,
                      y_uniform, (float)c, (float)(1.0 - c), (float)(1.0 / (double)lam), out, r_out,
                      per_image);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// fixed-ratio blend (d3f/balance_training_images/lit_module.py:109-121): out = sqrt(1-r[b])*x + sqrt(r[b])*noise
+int noise_blend_fixed_launch(const float* x, const float* noise, const float* r, float* out, int B, long per_image,
+                             hipStream_t stream) {
+  D3F_CHECK(per_image % 4 == 0, "noise_blend: per-image element count %ld not a multiple of 4", per_image);
+  if (B == 0 || per_image == 0) return 0;
+  long bx = (per_image / 4 + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(noise_blend_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, x, noise, r, 0.f, 0.f,
+                     -1.f, out, (float*)nullptr, per_image);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// per-image mean absolute error (compute_difficulty_loss, d3f/balance_training_images/lit_module.py:139-142):
+// L1_PARTS partial sums per image, then one thread block per image adds them in a fixed order (f64)
+constexpr int L1_PARTS = 64;
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                         double* __restrict__ partial, long per_image) {
+  __shared__ double red[256];
+  const int b = blockIdx.y;
+  const float* pp = p + (long)b * per_image;
+  const float* tt = t + (long)b * per_image;
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_image; i += (long)gridDim.x * 256)
+    s += (double)fabsf(pp[i] - tt[i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(long)b * L1_PARTS + blockIdx.x] = red[0];
+}
+__global__ void l1_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, long per_image) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  for (int i = 0; i < L1_PARTS; ++i) s += partial[(long)b * L1_PARTS + i];
+  out[b] = (float)(s / (double)per_image);
+}
+size_t l1_per_image_workspace_bytes(int B) { return (size_t)B * L1_PARTS * sizeof(double) + 64; }
+int l1_per_image_launch(const float* pred, const float* target, float* out, void* workspace, int B, long per_image,
+                        hipStream_t stream) {
+  if (B == 0) return 0;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_PARTS, (unsigned)B), dim3(256), 0, stream, pred, target, partial,
+                     per_image);
+  hipLaunchKernelGGL(l1_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, partial, out, B, per_image);
   D3F_HIP(hipGetLastError());
   return 0;
 }

@@ -99,6 +99,11 @@ int pack_all_launch(int dtype, const float* params, void* ws, const PackTable& t
 // ---- noise blend (K12), loss (K13), Adam (K14), EMA (K15) --------------------------------
 int noise_blend_launch(const float* x, const float* noise, const float* y_uniform, float lam,
                        float* out, float* r_out, int B, long per_image, hipStream_t stream);
+int noise_blend_fixed_launch(const float* x, const float* noise, const float* r, float* out, int B, long per_image,
+                             hipStream_t stream);
+size_t l1_per_image_workspace_bytes(int B);
+int l1_per_image_launch(const float* pred, const float* target, float* out, void* workspace, int B, long per_image,
+                        hipStream_t stream);
 size_t loss_workspace_floats(int B, int H, int W);
 int mse_ssim_loss_launch(const float* pred, const float* target, float in_min, float in_max,
                          float* loss_out /*[3]: loss, mse, ssim*/, float* grad_pred, float* workspace,

@@ -173,6 +173,29 @@ def noise_blend(x, noise, y_uniform, lam, return_r=False):
     return (out, r) if return_r else out
 
 
+def noise_blend_fixed(x, noise, ratio):
+    """sqrt(1-r)*x + sqrt(r)*noise with one ratio for every image (float) or a per-image tensor [B]."""
+    x = x.contiguous().float()
+    B = x.shape[0]
+    r = ratio if torch.is_tensor(ratio) else torch.ones(B, device=_dev(x)) * float(ratio)
+    r = r.to(device=_dev(x), dtype=torch.float32).reshape(-1).contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().d3f_noise_blend_fixed(ptr(x), ptr(noise.contiguous().float()), ptr(r), ptr(out), B,
+                                           x.numel() // max(B, 1), stream_ptr()))
+    return out
+
+
+def l1_per_image(pred, target):
+    """mean |pred - target| over each image: [B] f32."""
+    L = _lib.lib()
+    pred, target = pred.contiguous().float(), target.contiguous().float()
+    B = pred.shape[0]
+    ws = torch.empty(L.d3f_l1_per_image_workspace_bytes(B), dtype=torch.uint8, device=_dev(pred))
+    out = torch.empty(B, dtype=torch.float32, device=pred.device)
+    check(L.d3f_l1_per_image(ptr(pred), ptr(target), ptr(out), ptr(ws), B, pred.numel() // max(B, 1), stream_ptr()))
+    return out
+
+
 def mse_ssim_loss(pred, target, in_min=-1.0, in_max=1.0):
     """returns (loss[3] = {loss, mse, ssim} device tensor, grad wrt pred)."""
     L = _lib.lib()

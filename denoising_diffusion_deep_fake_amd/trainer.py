@@ -114,7 +114,7 @@ def _to_device(x, device):
 class Trainer:
     def __init__(self, max_epochs=1, max_steps=-1, callbacks=None, log_every_n_steps=50, gpus=None,
                  accelerator=None, devices=None, default_root_dir="lightning_logs", flush_every=100,
-                 enable_checkpointing=True, limit_train_batches=None):
+                 enable_checkpointing=True, limit_train_batches=None, limit_val_batches=None):
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.callbacks = list(callbacks or [])
         self.log_every_n_steps = log_every_n_steps
@@ -122,6 +122,7 @@ class Trainer:
         self.flush_every = flush_every
         self.enable_checkpointing = enable_checkpointing
         self.limit_train_batches = limit_train_batches
+        self.limit_val_batches = limit_val_batches
         self.global_step = 0
         self.current_epoch = 0
         self.logger = None
@@ -182,6 +183,22 @@ class Trainer:
         self._metric_rows = []
 
     # ---- fit ----------------------------------------------------------------------------------------
+    def _run_validation(self, model, device):
+        """Lightning's per-epoch validation loop for modules that define it (balance_training_images): eval mode,
+        no grad, validation_step over val_dataloader(), then validation_epoch_end(outputs)."""
+        if not (hasattr(model, "validation_step") and hasattr(model, "val_dataloader")):
+            return
+        model.eval()
+        outputs = []
+        with torch.no_grad():
+            for batch_idx, batch in enumerate(model.val_dataloader()):
+                if self.limit_val_batches is not None and batch_idx >= self.limit_val_batches:
+                    break
+                outputs.append(model.validation_step(_to_device(batch, device), batch_idx))
+            if outputs and hasattr(model, "validation_epoch_end"):
+                model.validation_epoch_end(outputs)
+        model.train()
+
     def fit(self, model, ckpt_path=None):
         if not torch.cuda.is_available():
             raise RuntimeError("training needs an MI355X (HIP device); there is no CPU path")
@@ -250,6 +267,7 @@ class Trainer:
                     break
             for s in self.lr_schedulers:
                 s.step()
+            self._run_validation(model, device)
             for cb in callbacks:
                 cb.on_train_epoch_end(self, model)
             self._flush_metrics()

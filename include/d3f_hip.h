@@ -174,6 +174,15 @@ int d3f_affine_warp(const float* in, const float* theta, float* out, int B, int 
  *   r = (1/lam) * log(1 / (y*(1-c) + c)), c = exp(-lam);  out = sqrt(1-r)*x + sqrt(r)*noise */
 int d3f_noise_blend(const float* x, const float* noise, const float* y_uniform, float lam, float* out,
                     float* r_out_or_null, int B, int64_t per_image, void* stream);
+/* blend_fixed_amount_of_noise_with_each_sample (d3f/balance_training_images/lit_module.py:109-121) given the
+ * caller's noise and the per-image ratios r [B] (device): out = sqrt(1-r)*x + sqrt(r)*noise */
+int d3f_noise_blend_fixed(const float* x, const float* noise, const float* r, float* out, int B, int64_t per_image,
+                          void* stream);
+/* compute_difficulty_loss (d3f/balance_training_images/lit_module.py:139-142): out[b] = mean |prediction - target|
+ * over image b; deterministic two-pass sum (f64 partials in the workspace) */
+size_t d3f_l1_per_image_workspace_bytes(int B);
+int d3f_l1_per_image(const float* prediction, const float* target, float* out, void* workspace, int B,
+                     int64_t per_image, void* stream);
 /* MseStructuralSimilarityLoss(input_min, input_max)(prediction, target)
  * (d3f/loss_functions/structural_similarity_loss.py:14-26; piqa.SSIM defaults) on NCHW f32
  * [B][3][H][W]: loss_out = {loss, mse, ssim}; grad_pred = d loss / d prediction. */

@@ -8,6 +8,8 @@ PINNED by tests/golden (generated from the reference's own functions):
     randn_like(batch) first, then rand(B,1,1,1).
   * tensor_to_uint8_denormalised -- d3f/train_deep_fake/lit_module.py:285-300
     (.int() truncation BEFORE clamp).
+  * blend_fixed_amount_of_noise / difficulty_loss / difficulty_index --
+    d3f/balance_training_images/lit_module.py:109-121, 139-142, 181-193 (tests/golden/balance.npz).
 PARITY UNPINNED (un-vendored `ema_pytorch`, restated from upstream defaults,
 SURVEY.md Appendix A.3): EMA.
 """
@@ -43,6 +45,26 @@ def blend_with_given_noise(batch, noise, r):
     the Gaussian noise / ratio are supplied explicitly)."""
     r = r.view(-1, 1, 1, 1)
     return torch.sqrt(1 - r) * batch + torch.sqrt(r) * noise
+
+
+def blend_fixed_amount_of_noise(batch, ratio_of_noise, noise=None):
+    # balance_training_images/lit_module.py:109-121
+    if noise is None:
+        noise = torch.randn_like(batch)
+    r = torch.ones((batch.shape[0], 1, 1, 1), device=batch.device) * ratio_of_noise
+    return torch.sqrt(1 - r) * batch + torch.sqrt(r) * noise
+
+
+def difficulty_loss(predicted, target):
+    # balance_training_images/lit_module.py:139-142: per-image mean absolute error
+    return torch.abs(predicted - target).mean(dim=(1, 2, 3))
+
+
+def difficulty_index(loss, number_of_classes):
+    # balance_training_images/lit_module.py:181-193: min-max normalise, clamp below 1, bin
+    loss_normalised = (loss - loss.min()) / (loss.max() - loss.min())
+    loss_normalised = loss_normalised.clamp(0, 0.99999)
+    return (loss_normalised * number_of_classes).long()
 
 
 def tensor_to_uint8_denormalised(tensor, mean, std):

@@ -16,6 +16,9 @@ import*; every golden value below comes from code that does not touch a mock:
   * LitModule.tensor_cv2_to_denormalised integer semantics
         (d3f/train_deep_fake/lit_module.py:285-296; the trailing cv2 RGB->BGR flip is
         mocked, so the fixture stores the tensor handed to it = HWC uint8 RGB)
+  * balance_training_images LitModule: blend_fixed_amount_of_noise_with_each_sample,
+    compute_difficulty_loss, compute_difficulty_index_for_each_loss
+        (d3f/balance_training_images/lit_module.py:109-121, 139-142, 181-193)
 Only data (inputs / outputs) is written; no reference source is copied.
 """
 import sys
@@ -140,6 +143,29 @@ def main():
     den["tensor"], den["mean"], den["std"] = tin.numpy(), mean.numpy(), std.numpy()
     den["uint8_rgb_hwc"] = captured["img"]
     np.savez_compressed(OUT / "denormalise.npz", **den)
+    # ---- (5) balance_training_images first-party arithmetic -----------------------------
+    sys.modules.setdefault("d3f.helpers", mock.MagicMock(name="d3f.helpers"))
+    from d3f.balance_training_images.lit_module import LitModule as BalanceLit
+    bal = {}
+    g = torch.Generator().manual_seed(21)
+    xb = torch.tanh(torch.randn(5, 3, 8, 8, generator=g))
+    bal["x"] = xb.numpy()
+    for ratio in (0.7, 0.25):
+        self = SimpleNamespace(hparams=SimpleNamespace(ratio_of_noise=ratio), device=torch.device("cpu"))
+        torch.manual_seed(3)
+        bal[f"blend_ratio{ratio}_out"] = BalanceLit.blend_fixed_amount_of_noise_with_each_sample(self, xb).numpy()
+        torch.manual_seed(3)
+        bal[f"blend_ratio{ratio}_noise"] = torch.randn_like(xb).numpy()
+    pred = torch.randn(5, 3, 8, 8, generator=g)
+    bal["pred"] = pred.numpy()
+    dl = BalanceLit.compute_difficulty_loss(SimpleNamespace(), pred, xb)
+    bal["difficulty_loss"] = dl.numpy()
+    losses = torch.tensor([0.31, 0.05, 0.95, 0.5, 0.050001, 0.949, 0.2, 0.77, 0.95, 0.05])
+    bal["losses"] = losses.numpy()
+    for ncls in (10, 4):
+        self = SimpleNamespace(hparams=SimpleNamespace(number_of_classes=ncls))
+        bal[f"difficulty_index_{ncls}"] = BalanceLit.compute_difficulty_index_for_each_loss(self, losses).numpy()
+    np.savez_compressed(OUT / "balance.npz", **bal)
     print("wrote", [p.name for p in OUT.glob("*.npz")])
 
 

@@ -302,3 +302,24 @@ def test_layout_roundtrip(ops):
     h = ops.nchw_to_nhwc(x.cuda(), 4)
     assert h.shape == (2, 8, 10, 4) and torch.equal(h[..., 3].cpu(), torch.zeros(2, 8, 10))
     assert torch.equal(ops.nhwc_to_nchw(h, 3).cpu(), x)
+
+
+def test_balance_kernels_match_reference_golden(ops, golden_dir):
+    """fixed-ratio blend and per-image L1 (balance_training_images) against vectors produced by the reference."""
+    g = np.load(golden_dir / "balance.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    for ratio in (0.7, 0.25):
+        out = ops.noise_blend_fixed(x, torch.from_numpy(g[f"blend_ratio{ratio}_noise"]).cuda(), ratio)
+        assert torch.equal(out.cpu(), torch.from_numpy(g[f"blend_ratio{ratio}_out"]))   # bit-exact
+    dl = ops.l1_per_image(torch.from_numpy(g["pred"]).cuda(), x)
+    assert max_rel(dl.cpu(), torch.from_numpy(g["difficulty_loss"])) < 1e-6
+    # a size where every partial block has work, and a per-image ratio tensor
+    big_p, big_t = torch.randn(3, 3, 64, 96), torch.randn(3, 3, 64, 96)
+    ref = (big_p - big_t).abs().double().mean(dim=(1, 2, 3)).float()
+    assert max_rel(ops.l1_per_image(big_p.cuda(), big_t.cuda()).cpu(), ref) < 1e-6
+    r = torch.tensor([0.1, 0.5, 0.9])
+    want = torch.sqrt(1 - r.view(-1, 1, 1, 1)) * big_p + torch.sqrt(r.view(-1, 1, 1, 1)) * big_t
+    # 1 ulp: torch's CPU sqrt is not correctly rounded on every host (sqrt(0.9f) comes out one ulp high on the GPU
+    # box's CPU; the kernel's __fsqrt_rn value is the correctly rounded one) -- the reference-generated fixtures
+    # above are matched bit for bit
+    assert max_rel(ops.noise_blend_fixed(big_p.cuda(), big_t.cuda(), r).cpu(), want) < 2.5e-7

@@ -106,3 +106,16 @@ def test_ema_schedule():
     assert ema.initted.item()
     d = ema.get_current_decay()
     assert abs(d - (1 - 2 ** (-2 / 3))) < 1e-9
+
+
+def test_balance_first_party_matches_reference_golden(golden_dir):
+    g = np.load(golden_dir / "balance.npz")
+    x = torch.from_numpy(g["x"])
+    for ratio in (0.7, 0.25):
+        out = oracle.blend_fixed_amount_of_noise(x, ratio, noise=torch.from_numpy(g[f"blend_ratio{ratio}_noise"]))
+        assert torch.equal(out, torch.from_numpy(g[f"blend_ratio{ratio}_out"]))
+    dl = oracle.difficulty_loss(torch.from_numpy(g["pred"]), x)
+    assert torch.equal(dl, torch.from_numpy(g["difficulty_loss"]))
+    for ncls in (10, 4):
+        idx = oracle.difficulty_index(torch.from_numpy(g["losses"]), ncls)
+        assert torch.equal(idx, torch.from_numpy(g[f"difficulty_index_{ncls}"]))
