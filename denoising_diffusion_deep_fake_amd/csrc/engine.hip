@@ -603,7 +603,14 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
   static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob
   if (!serial && side_ == nullptr) {
-    D3F_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
+    // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
+    // D3F_SIDE_PRIORITY=0 turns it off).  A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
+    // left to the caller's stream) was tried and halves the throughput on this platform.
+    int least = 0, greatest = 0;
+    D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
+    D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
     for (int i = 0; i < NDY; ++i) {
       D3F_HIP(hipEventCreateWithFlags(&ev_dy_[i], hipEventDisableTiming));
       D3F_HIP(hipEventCreateWithFlags(&ev_wg_[i], hipEventDisableTiming));
