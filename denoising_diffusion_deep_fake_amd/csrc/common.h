@@ -126,6 +126,14 @@ struct ConvParams {
   int mode;
   int relu;
   double flops;        // algorithmic FLOPs (2*MAC, unpadded channels) of this launch, for profiling
+  // CONV_DGRAD, optional: the BatchNorm-backward reduction of the layer that CONSUMES this gradient, fused
+  // into the epilogue (single destination, no accumulate): per row block the column sums of
+  //   dz = dX * (y*scale + shift > 0)   and   dz * (y - mean) * invstd
+  // go to bn_partial[stat_rows][Cout][2]; y = that layer's raw conv output, bn_coef = its mean | invstd |
+  // scale | shift arrays (Cout floats each, contiguous).
+  const void* bn_y;
+  const float* bn_coef;
+  float* bn_partial;
 };
 
 struct ConvTile {

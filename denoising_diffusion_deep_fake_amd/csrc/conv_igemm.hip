@@ -798,6 +798,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         store4(dst, v);
       }
     }
+    if (p.bn_partial != nullptr) {
+      // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, no accumulate):
+      // column sums over this tile's rows of dz and dz * xhat, with the ReLU mask recomputed from y by the
+      // forward's own arithmetic
+      constexpr int NG = 256 / BN;
+      const int col = tid % BN, rg = tid / BN;
+      const int nn = n0 + col, C = p.Cout;
+      const bool cok = nn < C;
+      const float mu = cok ? p.bn_coef[nn] : 0.f, is = cok ? p.bn_coef[C + nn] : 0.f;
+      const float sc = cok ? p.bn_coef[2 * C + nn] : 0.f, sf = cok ? p.bn_coef[3 * C + nn] : 0.f;
+      const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+      float s1 = 0.f, s2 = 0.f;
+      for (int row = rg; row < BM; row += NG) {
+        const int m = m0 + row;
+        if (cok && m < p.M) {
+          const float yy = to_f32<T>(yb[(long)m * C + nn]);
+          const float g = (yy * sc + sf) > 0.f ? Cs[row * LDC + col] : 0.f;
+          s1 += g;
+          s2 += g * ((yy - mu) * is);
+        }
+      }
+      __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
+      float* red = reinterpret_cast<float*>(lds);
+      red[(rg * BN + col) * 2 + 0] = s1;
+      red[(rg * BN + col) * 2 + 1] = s2;
+      __syncthreads();
+      if (tid < BN) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          a1 += red[(g * BN + tid) * 2 + 0];
+          a2 += red[(g * BN + tid) * 2 + 1];
+        }
+        const int c = n0 + tid;
+        if (c < C) {
+          p.bn_partial[((long)tile_m * C + c) * 2 + 0] = a1;
+          p.bn_partial[((long)tile_m * C + c) * 2 + 1] = a2;
+        }
+      }
+    }
   }
 }
 
@@ -861,9 +901,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
         if (accum) x += to_f32<T>(dst[k]);
         dst[k] = from_f32<T>(x);
       }
+      if (p.bn_partial != nullptr) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel)
+        const int C = p.Cout;
+        const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float yy = to_f32<T>(yb[e + k]);
+          const float g = (yy * p.bn_coef[2 * C + n + k] + p.bn_coef[3 * C + n + k]) > 0.f ? vv[k] : 0.f;
+          s1[k] += g;
+          s2[k] += g * ((yy - p.bn_coef[n + k]) * p.bn_coef[C + n + k]);
+        }
+      }
     }
   }
-  if (p.mode == CONV_RAW_STATS && p.stats != nullptr) {
+  const bool fused_bn = p.mode == CONV_DGRAD && p.bn_partial != nullptr;
+  if ((p.mode == CONV_RAW_STATS && p.stats != nullptr) || fused_bn) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       red[(threadIdx.x * 4 + k) * 2 + 0] = s1[k];
@@ -875,7 +927,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
       const int v = c >> 2, k = c & 3;
       float s = 0.f;
       for (int rr = 0; rr < RP; ++rr) s += red[(((rr * VC + v) * 4) + k) * 2 + which];
-      p.stats[((long)blockIdx.x * p.CoutPad + c) * 2 + which] = s;
+      if (fused_bn) p.bn_partial[((long)blockIdx.x * p.Cout + c) * 2 + which] = s;
+      else p.stats[((long)blockIdx.x * p.CoutPad + c) * 2 + which] = s;
     }
   }
 }

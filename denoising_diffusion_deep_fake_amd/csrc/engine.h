@@ -55,6 +55,10 @@ struct BwdOp {
   int unit = -1;
   // BW_UNIT
   int dA = -1;          // gradient tensor wrt the unit's output activation (grad id)
+  // BatchNorm-backward reduce fusion: this op's data gradient is the ONLY writer of the next unit op's dA and
+  // that unit recomputes its ReLU mask from y -> its reduction rides in this dgrad's epilogue
+  int fuse_for_unit = -1;   // producer side: unit whose (dbeta, dgamma) partial sums this dgrad also emits
+  int fused_rows = 0;       // consumer side: > 0 = partial rows already written by the producer (skip the reduce)
   bool mask = true;     // apply the ReLU mask of unit.a
   int dres = -1;        // grad tensor receiving dz (identity / downsample path) or -1
   bool dres_acc = false;

@@ -348,6 +348,35 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   }
   if (int rc = emit_unit(conv1, grad_of[f1], true, -1, false)) return rc;
 
+  // ---- BatchNorm-backward reduce fusion (f32 storage): op j's data gradient -> next unit op's reduction ----
+  if (dtype == D3F_F32 && getenv("D3F_NO_FUSED_BN_REDUCE") == nullptr) {
+    auto writers = [&](int gid) {
+      int n = 0;
+      for (const BwdOp& o : bwd_ops) {
+        if ((o.kind == BW_UNIT || o.kind == BW_HEAD) && units[o.unit].need_dgrad && !o.dst0_is_full_scratch && o.dst0 == gid) ++n;
+        if ((o.kind == BW_UNIT || o.kind == BW_HEAD) && o.dst1 == gid) ++n;
+        if (o.kind == BW_UNIT && o.dres == gid) ++n;
+        if ((o.kind == BW_SUM2X2 || o.kind == BW_POOL) && o.dst0 == gid) ++n;
+      }
+      return n;
+    };
+    for (size_t j = 0; j + 1 < bwd_ops.size(); ++j) {
+      BwdOp& pj = bwd_ops[j];
+      if (!(pj.kind == BW_UNIT || pj.kind == BW_HEAD)) continue;
+      const Unit& up = units[pj.unit];
+      if (!up.need_dgrad || pj.dst0_is_full_scratch || pj.dst1 >= 0 || pj.acc0 || pj.dst0 < 0) continue;
+      BwdOp& ck = bwd_ops[j + 1];  // the consumer must be the very next op (bnpart is a stream-ordered scratch)
+      if (ck.kind != BW_UNIT || ck.dA != pj.dst0 || writers(pj.dst0) != 1) continue;
+      const Unit& uc = units[ck.unit];
+      if (!(uc.bn && ck.mask && uc.res_tensor < 0 && uc.res_unit < 0)) continue;
+      D3F_CHECK(up.dgrad.Cout == uc.Cout && up.dgrad.M == B * uc.Ho * uc.Wo && up.dgrad.out_c0 == up.dgrad.Cout,
+                "plan: fused BatchNorm reduce shape mismatch (%s -> %s)", up.conv_name.c_str(), uc.conv_name.c_str());
+      pj.fuse_for_unit = ck.unit;
+      ck.fused_rows = up.dgrad.splitk > 1 ? up.dgrad.stat_rows : up.dgrad.tiles_m;
+      bnpart_bytes = std::max(bnpart_bytes, (size_t)ck.fused_rows * uc.Cout * 2 * sizeof(float));
+    }
+  }
+
   // ---- scratch ------------------------------------------------------------------------
   stats_off = alloc(stats_bytes);
   bnpart_off = alloc(bnpart_bytes);
@@ -662,9 +691,12 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       const void* amask = (op.mask && !from_y) ? T(u.a) : nullptr;
       const float* msc = from_y ? coef_ptr(ws, u, 2) : nullptr;
       const float* msf = from_y ? coef_ptr(ws, u, 3) : nullptr;
-      if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
-                                        u.Cout, s, msc, msf))
+      if (op.fused_rows > 0) {
+        nb = op.fused_rows;  // the producing data gradient already left the partial sums in bnpart
+      } else if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
+                                               u.Cout, s, msc, msf)) {
         return rc;
+      }
       if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
                                           grads + u.g_off, grads + u.b_off, 0, k, s))
         return rc;
@@ -707,6 +739,12 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
       d.acc1 = op.acc1 ? 1 : 0;
       d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+      if (op.fuse_for_unit >= 0) {
+        const Unit& uc = units[op.fuse_for_unit];
+        d.bn_y = T(uc.y);
+        d.bn_coef = coef_ptr(ws, uc, 0);
+        d.bn_partial = reinterpret_cast<float*>(ws + bnpart_off);
+      }
       if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
     }
   }
