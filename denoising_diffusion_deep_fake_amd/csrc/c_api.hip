@@ -304,7 +304,7 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
   if (int rc = wgrad_params(dtype, d, w)) return rc;
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
   w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
-  if (int rc = wgrad_launch(w, sdt(dtype), (hipStream_t)stream)) return rc;
+  if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
   return wgrad_reduce_launch(w.partial, w.splits, w.Cout, d->Cout, d->C0 + d->C1, d->CinReal, d->KH, d->KW,
                              dw, 0, (hipStream_t)stream);
 }

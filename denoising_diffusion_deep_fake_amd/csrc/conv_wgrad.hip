@@ -32,18 +32,52 @@ template <> __device__ __forceinline__ void lds_store_as_f32<bf16_t>(float* dst,
   *reinterpret_cast<uint4*>(dst + 4) = make_uint4(v.z << 16, v.z & 0xffff0000u, v.w << 16, v.w & 0xffff0000u);
 }
 
+// 4 fp32 -> three 8-byte groups of bf16: the exact 3-way truncation split of conv_igemm.hip's x3 mode
+__device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, uint2& l) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t r1[4], r2[4];
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const f32x2 f = {__uint_as_float(x[e]), __uint_as_float(x[e + 1])};
+    const f32x2 hi = {__uint_as_float(x[e] & 0xffff0000u), __uint_as_float(x[e + 1] & 0xffff0000u)};
+    const f32x2 a = f - hi;
+    r1[e] = __float_as_uint(a.x);
+    r1[e + 1] = __float_as_uint(a.y);
+    const f32x2 mid = {__uint_as_float(r1[e] & 0xffff0000u), __uint_as_float(r1[e + 1] & 0xffff0000u)};
+    const f32x2 b = a - mid;
+    r2[e] = __float_as_uint(b.x);
+    r2[e + 1] = __float_as_uint(b.y);
+  }
+  constexpr uint32_t SEL = 0x07060302u;
+  h = make_uint2(__builtin_amdgcn_perm(x[1], x[0], SEL), __builtin_amdgcn_perm(x[3], x[2], SEL));
+  m = make_uint2(__builtin_amdgcn_perm(r1[1], r1[0], SEL), __builtin_amdgcn_perm(r1[3], r1[2], SEL));
+  l = make_uint2(__builtin_amdgcn_perm(r2[1], r2[0], SEL), __builtin_amdgcn_perm(r2[3], r2[2], SEL));
+}
+
 // T = activation type in memory (f32 or bf16).  The contraction itself runs on the f32 MFMA for both:
 // bf16 operands are widened when they are staged into LDS (exact), accumulation is f32.
-template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT>
+//
+// X3 (64x64 tile, fp32 operands): the f32x3 contraction of conv_igemm.hip for the weight gradient.  Both operands
+// are k-strided here (k = pixel, the image is [pixel][channel]), so the bf16 planes are staged as
+// [32-channel subtile][32 pixels][32 channels] with 64-byte rows and the MFMA operands (8 consecutive k of one
+// channel per lane) are gathered with ds_read_b64_tr_b16, the hardware transposing read of gfx950: two reads
+// per fragment, conflict-free because the 4 rows x 64 B a half-wave touches are contiguous.
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
+  static_assert(!X3 || (sizeof(T) == 4 && BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1),
+                "x3 weight gradient: fp32 operands, 64x64 tile");
   constexpr int TM = BMW / WGM, TN = BNW / WGN, FM = TM / 32, FN = TN / 32;
   constexpr int LY = BMW + 4, LX = BNW + 4;    // LDS row strides (floats), 16-B aligned rows
   constexpr int VY = BMW / VE, VX = BNW / VE;  // 16-byte global vectors per row
   constexpr int NVY = (KP * VY + 255) / 256, NVX = (KP * VX + 255) / 256;
   static_assert(WGM * WGN * KSPLIT == 4, "4 waves");
   constexpr int RED = (KSPLIT > 1) ? KSPLIT * 32 * 32 : 1;
-  constexpr int LDS_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
+  // x3: per operand 3 planes x 2 subtiles x [32 pixels][32 channels] bf16
+  constexpr int X3_SUB = KP * 64, X3_PLANE = 2 * X3_SUB, X3_OP = 3 * X3_PLANE;  // bytes
+  constexpr int F32_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
+  constexpr int LDS_FLOATS = X3 ? 2 * X3_OP / 4 : F32_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* Ys = lds;
   float* Xs = lds + KP * LY;
@@ -170,30 +204,93 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
   if (chunk_begin < chunk_end) load_chunk(chunk_begin);
   const int fr = lane & 31, fh = lane >> 5;
-  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+  if constexpr (X3) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
+    // staging: this thread's 4 channels of one pixel -> 8 bytes per plane
+    const int ywoff = (ycv >> 3) * X3_SUB + (ycv & 7) * 8, xwoff = (xcv >> 3) * X3_SUB + (xcv & 7) * 8;
+    // fragment gather: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies row q, channels 4p..
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int rd_lane = ((grp >> 1) * 8 + q) * 64 + ((grp & 1) * 16 + 4 * pq) * 2;  // + s*16*64 + h*4*64
+    const unsigned char* ya = lb + wm * X3_SUB + rd_lane;
+    const unsigned char* xa = lb + X3_OP + wn * X3_SUB + rd_lane;
+    auto frag = [&](const unsigned char* base, int pl, int s) {
+      union { uint4 u; v4s h[2]; } f;
 #pragma unroll
-    for (int i = 0; i < NVY; ++i)
-      if (yrow0 + i * YRS < KP) lds_store_as_f32<T>(&Ys[(yrow0 + i * YRS) * LY + ycv * VE], ry[i]);
+      for (int h = 0; h < 2; ++h)
+        f.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(base + pl * X3_PLANE + s * 16 * 64 + h * 4 * 64));
+      return f.u;
+    };
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
 #pragma unroll
-    for (int i = 0; i < NVX; ++i)
-      if (xrow0 + i * XRS < KP) lds_store_as_f32<T>(&Xs[(xrow0 + i * XRS) * LX + xcv * VE], rx[i]);
-    __syncthreads();
-    if (ch + 1 < chunk_end) load_chunk(ch + 1);
+      for (int i = 0; i < NVY; ++i) {
+        const int row = yrow0 + i * YRS;
+        if (row < KP) {
+          uint2 h, m, l;
+          wg_split3x4(ry[i], h, m, l);
+          unsigned char* d = lb + row * 64 + ywoff;
+          *reinterpret_cast<uint2*>(d) = h;
+          *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
+          *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+        }
+      }
 #pragma unroll
-    for (int kk = wk; kk < KP / 2; kk += KSPLIT) {
-      const int k = 2 * kk + fh;
-      float a[FM], b[FN];
+      for (int i = 0; i < NVX; ++i) {
+        const int row = xrow0 + i * XRS;
+        if (row < KP) {
+          uint2 h, m, l;
+          wg_split3x4(rx[i], h, m, l);
+          unsigned char* d = lb + X3_OP + row * 64 + xwoff;
+          *reinterpret_cast<uint2*>(d) = h;
+          *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
+          *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+        }
+      }
+      __syncthreads();
+      if (ch + 1 < chunk_end) load_chunk(ch + 1);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = Ys[k * LY + wm * TM + i * 32 + fr];
+      for (int s = 0; s < KP / 16; ++s) {
+        uint4 a[3], b[3];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = Xs[k * LX + wn * TN + j * 32 + fr];
+        for (int pl = 0; pl < 3; ++pl) {
+          a[pl] = frag(ya, pl, s);
+          b[pl] = frag(xa, pl, s);
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 6; ++t)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a[PA[t]]),
+                                                              *reinterpret_cast<const bf16x8*>(&b[PB[t]]), acc[0][0], 0, 0, 0);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+  #pragma unroll
+      for (int i = 0; i < NVY; ++i)
+        if (yrow0 + i * YRS < KP) lds_store_as_f32<T>(&Ys[(yrow0 + i * YRS) * LY + ycv * VE], ry[i]);
+  #pragma unroll
+      for (int i = 0; i < NVX; ++i)
+        if (xrow0 + i * XRS < KP) lds_store_as_f32<T>(&Xs[(xrow0 + i * XRS) * LX + xcv * VE], rx[i]);
+      __syncthreads();
+      if (ch + 1 < chunk_end) load_chunk(ch + 1);
+  #pragma unroll
+      for (int kk = wk; kk < KP / 2; kk += KSPLIT) {
+        const int k = 2 * kk + fh;
+        float a[FM], b[FN];
+  #pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = Ys[k * LY + wm * TM + i * 32 + fr];
+  #pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = Xs[k * LX + wn * TN + j * 32 + fr];
+  #pragma unroll
+        for (int i = 0; i < FM; ++i)
+  #pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
   }
 
   // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -322,14 +419,21 @@ size_t wgrad_partial_floats(const WgradParams& p) {
   return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
 }
 
-template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream) {
+template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream, bool x3) {
   const dim3 block(256);
-  if (bm == 128)
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1>), grid, block, 0, stream, p);
-  else if (bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1>), grid, block, 0, stream, p);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4>), grid, block, 0, stream, p);
+  if (bm == 128) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1, false>), grid, block, 0, stream, p);
+  } else if (bm == 64) {
+    if constexpr (sizeof(T) == 4) {
+      if (x3) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, 0, stream, p);
+  }
 }
 
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
@@ -337,7 +441,8 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   if (p.patch) {
     const bool prof = prof_enabled(PROF_WGRAD);
     if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
-    const int rc = wgrad_patch_launch(p, p.patch, dtype, stream);
+    // (the persistent patch kernel of the narrow layers stays on the fp32 MFMA in f32x3 mode)
+    const int rc = wgrad_patch_launch(p, p.patch, dtype == D3F_F32X3 ? D3F_F32 : dtype, stream);
     if (prof) prof_end(stream);
     return rc;
   }
@@ -346,8 +451,8 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits);
   const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
-  if (dtype == D3F_F32) wgrad_launch_t<float>(p, t.bm, grid, stream);
-  else wgrad_launch_t<bf16_t>(p, t.bm, grid, stream);
+  if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, t.bm, grid, stream, false);
+  else wgrad_launch_t<float>(p, t.bm, grid, stream, dtype == D3F_F32X3);
   if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());
   return 0;

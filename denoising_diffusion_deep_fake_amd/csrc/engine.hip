@@ -715,7 +715,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     g.src0 = T(u.in0);
     g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
     g.partial = wpart;
-    if (int rc = wgrad_launch(g, dtype, ws_stream)) return rc;
+    if (int rc = wgrad_launch(g, cdtype, ws_stream)) return rc;
     if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW,
                                      grads + u.w_off, 0, ws_stream))
       return rc;

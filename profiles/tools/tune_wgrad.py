@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from denoising_diffusion_deep_fake_amd import ops
 
+DT = {"f32": ops.F32, "f32x3": ops.F32X3}[os.environ.get("DT", "f32")]
 B = int(os.environ.get("B", 16))
 S = int(os.environ.get("S", 256))
 # name: (H, W (input), C0, C1, Cout, k, stride, pad, upsample0, count in the network)
@@ -43,7 +44,7 @@ for name, (H, W, C0, C1, Co, k, st, pd, up, cnt, creal) in shapes.items():
     dy = torch.randn(B, ho, wo, cop, device="cuda")
     try:
         for _ in range(3):
-            ops.conv_backward_weight(d, dy, s0, s1)
+            ops.conv_backward_weight(d, dy, s0, s1, DT)
     except Exception as e:
         print(f"{name:24s} ERR {str(e)[:80]}")
         continue
@@ -51,7 +52,7 @@ for name, (H, W, C0, C1, Co, k, st, pd, up, cnt, creal) in shapes.items():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ops.conv_backward_weight(d, dy, s0, s1)
+        ops.conv_backward_weight(d, dy, s0, s1, DT)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
