@@ -162,3 +162,24 @@ def test_rccl_backend_single_rank():
     ret = mgr.dict()
     _spawn_with_deadline(_rccl_worker, (_free_port(), ret), 1, seconds=200)
     assert ret.get("equal") is True and ret.get("finite") is True, dict(ret)
+
+
+def test_bench_contract_two_ranks(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) -- rehearsed with two
+    ranks sharing the one GPU over gloo: rank 0 prints exactly one JSON line with the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--batch", "4", "--size", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["value"] > 0 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
+    assert "roofline" in res and "cpu_baseline" not in res and "alt_f32x3" not in res   # N = 1 extras only
