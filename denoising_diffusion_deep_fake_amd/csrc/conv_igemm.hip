@@ -14,8 +14,11 @@
 // reads (16 rows x one 16-byte chunk per lane group) are bank-conflict free.  Fragments are
 // fed to v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact f32) or the bf16 32x32x16 / 16x16x32
 // forms; the per-lane k order is permuted identically for A and W, which leaves the sum
-// unchanged.  Global loads for k-tile t+1 are issued before the MFMAs of tile t
-// (register-staged prefetch, one LDS buffer, two barriers per k-tile).
+// unchanged.  Tiles with fewer than 256 rows run a two-stage LDS pipeline with ONE barrier per k-tile: while
+// the MFMAs consume tile t, tile t+1 is written to the other stage and the buffer loads of tile t+2 (t+3 in
+// the lean loop for plain gathers) are issued piece by piece behind individual MFMAs; the 256-row tiles of
+// the narrow layers keep one stage and two barriers.  An opt-in "x3" mode forms fp32 products on the bf16
+// matrix pipe from an exact 3-way split of both operands (see MmaX3 below).
 #include "common.h"
 
 #include <cstdio>
