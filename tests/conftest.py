@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libd3f_hip.so (build artefacts are git-ignored): build it once, exactly as
+    __graft_entry__.build() does, so that the suite does not depend on the order the driver runs things in."""
+    import shutil
+    import subprocess
+    csrc = ROOT / "denoising_diffusion_deep_fake_amd" / "csrc"
+    if not (csrc / "libd3f_hip.so").exists() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.run(["make", "-C", str(csrc), "-j8"], check=True, stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
