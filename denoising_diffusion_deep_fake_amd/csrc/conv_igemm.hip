@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // the load of one k-tile = a wave-uniform setup + (NVA + NVB) independent per-vector pieces
   // (address arithmetic + one buffer load each), so the main loop can emit the pieces one by one
   // between MFMAs.
+  const bool sc_pow2 = (Cin & (Cin - 1)) == 0;
+  const int sc_shift = __builtin_ctz((unsigned)Cin | 0x80000000u);
+  const unsigned sc_kw_magic = (65536u + (unsigned)p.KW - 1u) / (unsigned)p.KW;
   struct TileCtx {
     int kh, kw, c, kt;
     int tapvalid, parity_mask, Cs, sh, Hs, Ws;
@@ -305,10 +308,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     x.tapvalid = 1;
     x.from0 = true;
     if (SMALLC) {
+      // per-lane tap decode without integer divisions (two of them cost ~80 VALU per k-tile): the small-channel
+      // layers have power-of-two Cin, and tap / KW is a multiply-shift (exact for tap < 2^16 / KW)
       const int kk = kt * BKE + chunk * VE;
-      const int tap = kk / Cin;
+      const int tap = sc_pow2 ? (kk >> sc_shift) : kk / Cin;
       x.c = kk - tap * Cin;
-      x.kh = tap / p.KW;
+      x.kh = (int)(((unsigned)tap * sc_kw_magic) >> 16);
       x.kw = tap - x.kh * p.KW;
       x.tapvalid = tap < p.KH * p.KW ? 1 : 0;
     } else {
