@@ -81,3 +81,32 @@ def test_ema_decay_schedule_matches_oracle():
     for step in (0, 50, 101, 102, 150, 1000, 10 ** 7):
         ref.step.fill_(step)
         assert abs(ours.get_current_decay(step) - ref.get_current_decay()) < 1e-12
+
+
+def test_balance_host_logic_matches_reference_golden(tmp_path):
+    """balance_training_images host arithmetic (no kernels): binning against vectors produced by the reference,
+    concatenation of validation outputs, and the class list file."""
+    from pathlib import Path
+    import oracle  # noqa: F401  (same golden file pins the oracle in test_oracle_golden.py)
+    from denoising_diffusion_deep_fake_amd.balance_training_images.lit_module import LitModule
+    g = np.load(Path(__file__).resolve().parent / "golden" / "balance.npz")
+    losses = torch.from_numpy(g["losses"])
+    for ncls in (10, 4):
+        stub = type("S", (), {"hparams": AttributeDict(number_of_classes=ncls)})()
+        idx = LitModule.compute_difficulty_index_for_each_loss(stub, losses)
+        assert torch.equal(idx, torch.from_numpy(g[f"difficulty_index_{ncls}"]))
+    outs = [{"index": torch.tensor([2, 0]), "loss": torch.tensor([0.5, 0.1])},
+            {"index": torch.tensor([1]), "loss": torch.tensor([0.9])}]
+    cat = LitModule.concat_validation_output(None, outs)
+    assert cat["index"].tolist() == [2, 0, 1] and torch.allclose(cat["loss"], torch.tensor([0.5, 0.1, 0.9]))
+    (tmp_path / "images.txt").write_text("a.png\nb.png\nc.png\n")
+    stub = type("S", (), {"hparams": AttributeDict(input_image_list_path=str(tmp_path / "images.txt"), synthetic=False),
+                          "_data_path": lambda self: self.hparams["input_image_list_path"]})()
+    LitModule.write_output_list(stub, str(tmp_path / "out.txt"), cat["index"], torch.tensor([3, 0, 1]))
+    assert (tmp_path / "out.txt").read_text() == "a.png\t0\nb.png\t1\nc.png\t3\n"
+
+
+def test_cli_has_the_reference_commands():
+    from denoising_diffusion_deep_fake_amd.main import cli
+    assert {"train", "denoise", "balance"} <= set(cli.commands)
+    assert {"new", "resume", "modify"} <= set(cli.commands["train"].commands)
