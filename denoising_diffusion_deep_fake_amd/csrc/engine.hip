@@ -631,6 +631,10 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
   static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob
+  // timing-only ablation (wrong gradients): D3F_ABLATE_BACKWARD contains w (skip weight gradients), d (data
+  // gradients), b (BatchNorm backward kernels) -- what each class costs on the critical path
+  static const char* abl = getenv("D3F_ABLATE_BACKWARD");
+  const bool skip_w = abl && strchr(abl, 'w'), skip_d = abl && strchr(abl, 'd'), skip_b = abl && strchr(abl, 'b');
   if (!serial && side_ == nullptr) {
     // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
     // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
@@ -691,15 +695,19 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       const void* amask = (op.mask && !from_y) ? T(u.a) : nullptr;
       const float* msc = from_y ? coef_ptr(ws, u, 2) : nullptr;
       const float* msf = from_y ? coef_ptr(ws, u, 3) : nullptr;
-      if (op.fused_rows > 0) {
+      if (skip_b) {
+        nb = 1;
+      } else if (op.fused_rows > 0) {
         nb = op.fused_rows;  // the producing data gradient already left the partial sums in bnpart
       } else if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
                                                u.Cout, s, msc, msf)) {
         return rc;
       }
+      if (!skip_b)
       if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
                                           grads + u.g_off, grads + u.b_off, 0, k, s))
         return rc;
+      if (!skip_b)
       if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
                                        op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
                                        u.Cout, s, msc, msf))
@@ -715,7 +723,9 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     g.src0 = T(u.in0);
     g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
     g.partial = wpart;
+    if (!skip_w)
     if (int rc = wgrad_launch(g, cdtype, ws_stream)) return rc;
+    if (!skip_w)
     if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW,
                                      grads + u.w_off, 0, ws_stream))
       return rc;
@@ -725,7 +735,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       side_used = true;
     }
     // data gradient (main stream)
-    if (u.need_dgrad) {
+    if (u.need_dgrad && !skip_d) {
       ConvParams d = u.dgrad;
       d.src0 = dy;
       d.w = ws + u.wd_off;
