@@ -15,7 +15,6 @@ Differences, all outside the parity-checked arithmetic
 import math
 
 import torch
-import torch.nn.functional as F
 import torch.optim.lr_scheduler as schedulers
 from torch.utils.data import DataLoader
 
