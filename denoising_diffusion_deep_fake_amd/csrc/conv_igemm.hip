@@ -158,6 +158,43 @@ __device__ __forceinline__ void split3x4(const uint4& v, uint2& h, uint2& m, uin
   l = make_uint2(__builtin_amdgcn_perm(r2[1], r2[0], SEL), __builtin_amdgcn_perm(r2[3], r2[2], SEL));
 }
 
+// -DD3F_PHASE_TIMING (profiling builds only, profiles/tools/phase_timing.py): thread 0 of every workgroup adds the
+// duration of its prologue / main loop / epilogue (100 MHz wall clock ticks) to d3f_phase_acc[0..2], [3] counts
+// workgroups, [4] sums whole-workgroup lifetimes.
+#ifdef D3F_PHASE_TIMING
+__device__ unsigned long long d3f_phase_acc[8];
+struct PhaseTimer {
+  unsigned long long t0, t1, t2;
+  bool on;
+  __device__ PhaseTimer() : t0(wall_clock64()), t1(0), t2(0), on(threadIdx.x == 0) {}
+  __device__ ~PhaseTimer() {
+    if (on) {
+      const unsigned long long t3 = wall_clock64();
+      atomicAdd(&d3f_phase_acc[0], t1 - t0);
+      atomicAdd(&d3f_phase_acc[1], t2 - t1);
+      atomicAdd(&d3f_phase_acc[2], t3 - t2);
+      atomicAdd(&d3f_phase_acc[3], 1ull);
+      atomicAdd(&d3f_phase_acc[4], t3 - t0);
+    }
+  }
+};
+#define D3F_PHASE_BEGIN PhaseTimer phase_timer
+#define D3F_PHASE_LOOP phase_timer.t1 = wall_clock64()
+#define D3F_PHASE_EPILOGUE phase_timer.t2 = wall_clock64()
+extern "C" int d3f_debug_phase_read(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d3f_phase_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d3f_phase_acc), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define D3F_PHASE_BEGIN
+#define D3F_PHASE_LOOP
+#define D3F_PHASE_EPILOGUE
+#endif
+
 constexpr int LDS_ROW = 36;  // dwords per LDS row: 128 B of data + 16 B pad
 constexpr int X3_ROW = 16;   // x3 mode: dwords per LDS row of one bf16 plane (32 bf16, XOR-swizzled, no pad)
 
@@ -193,6 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int LDS_DW = NSTAGE * STAGE > CTILE ? NSTAGE * STAGE : CTILE;
   __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DW];
 
+  D3F_PHASE_BEGIN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
@@ -484,6 +522,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }(std::make_integer_sequence<int, NPIECE>{});
   };
 
+  D3F_PHASE_LOOP;
   if constexpr (FAST && DB) {
     // ---- lean main loop for plain gathers ---------------------------------------------------------
     // Microbenchmark (profiles/README.md): next to 16 MFMAs per k-tile, ~32 dependent SALU cost 30 % and
@@ -647,6 +686,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
   }  // DB
 
+  D3F_PHASE_EPILOGUE;
   // ---- epilogue ----------------------------------------------------------------------
   // accumulator element (i, j, r) of this lane = out[m][n] with
   //   MT=32: n_l = lane&31, m_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
