@@ -267,6 +267,7 @@ int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const 
                      const void* w_fwd, void* y, float* stats, void* workspace, void* stream) {
   ConvParams p;
   if (int rc = fwd_params(dtype, d, p, workspace != nullptr)) return rc;
+  if (d && d->B == 0) return 0;  // empty batch: nothing to compute (an empty tensor has a null data pointer)
   D3F_CHECK(src0 && w_fwd && y && (d->C1 == 0 || src1), "conv_forward: null argument");
   p.src0 = src0; p.src1 = src1; p.w = w_fwd; p.out0 = y; p.stats = stats; p.mode = CONV_RAW_STATS;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
@@ -276,6 +277,7 @@ int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, co
                            void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream) {
   ConvParams p;
   if (int rc = dgrad_params(dtype, d, p, workspace != nullptr)) return rc;
+  if (d && d->B == 0) return 0;
   D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
   p.src0 = dy; p.w = w_dgrad; p.out0 = dx0; p.out1 = dx1; p.acc0 = acc0; p.acc1 = acc1;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
@@ -302,6 +304,11 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
                              const void* src1, void* workspace, float* dw, void* stream) {
   WgradParams w;
   if (int rc = wgrad_params(dtype, d, w)) return rc;
+  if (d && d->B == 0) {  // empty batch: the gradient is zero
+    D3F_CHECK(dw, "conv_backward_weight: null argument");
+    D3F_HIP(hipMemsetAsync(dw, 0, (size_t)d->Cout * d->CinReal * d->KH * d->KW * sizeof(float), (hipStream_t)stream));
+    return 0;
+  }
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
   w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
   if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
@@ -357,6 +364,7 @@ int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int
   return sum2x2_launch(sdt(dtype), dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
 }
 int d3f_affine_warp(const float* in, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
+  if (B == 0) return 0;
   D3F_CHECK(in && theta && out && in != out, "affine_warp: null or aliased argument");
   D3F_CHECK(B >= 0 && C > 0 && H > 0 && W > 0, "affine_warp: bad shape");
   return affine_warp_launch(in, theta, out, B, C, H, W, (hipStream_t)stream);
@@ -374,18 +382,21 @@ int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
 // ---- training-step arithmetic ---------------------------------------------------------------
 int d3f_noise_blend(const float* x, const float* noise, const float* y_uniform, float lam, float* out,
                     float* r_out_or_null, int B, int64_t per_image, void* stream) {
+  if (B == 0 || per_image == 0) return 0;
   D3F_CHECK(x && noise && y_uniform && out, "noise_blend: null argument");
   return noise_blend_launch(x, noise, y_uniform, lam, out, r_out_or_null, B, (long)per_image,
                             (hipStream_t)stream);
 }
 int d3f_noise_blend_fixed(const float* x, const float* noise, const float* r, float* out, int B, int64_t per_image,
                           void* stream) {
+  if (B == 0 || per_image == 0) return 0;
   D3F_CHECK(x && noise && r && out, "noise_blend_fixed: null argument");
   return noise_blend_fixed_launch(x, noise, r, out, B, (long)per_image, (hipStream_t)stream);
 }
 size_t d3f_l1_per_image_workspace_bytes(int B) { return l1_per_image_workspace_bytes(B); }
 int d3f_l1_per_image(const float* prediction, const float* target, float* out, void* workspace, int B,
                      int64_t per_image, void* stream) {
+  if (B == 0) return 0;
   D3F_CHECK(prediction && target && out && workspace, "l1_per_image: null argument");
   return l1_per_image_launch(prediction, target, out, workspace, B, (long)per_image, (hipStream_t)stream);
 }

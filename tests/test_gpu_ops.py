@@ -323,3 +323,22 @@ def test_balance_kernels_match_reference_golden(ops, golden_dir):
     # box's CPU; the kernel's __fsqrt_rn value is the correctly rounded one) -- the reference-generated fixtures
     # above are matched bit for bit
     assert max_rel(ops.noise_blend_fixed(big_p.cuda(), big_t.cuda(), r).cpu(), want) < 2.5e-7
+
+
+def test_empty_batches_are_no_ops(ops):
+    """zero-sized inputs: every entry point returns without launching (no fault, no error)."""
+    z = torch.zeros(0, 3, 32, 32, device="cuda")
+    assert ops.noise_blend(z, z, torch.zeros(0, device="cuda"), 5.0).shape == z.shape
+    assert ops.noise_blend_fixed(z, z, 0.7).shape == z.shape
+    assert ops.l1_per_image(z, z).shape == (0,)
+    assert ops.affine_warp(z, torch.zeros(0, 2, 3, device="cuda")).shape == z.shape
+    d = ops.make_desc(0, 16, 16, 32, 0, 32, 3, 1, 1, False)
+    w = torch.randn(32, 32, 3, 3, device="cuda")
+    wf, wd = ops.pack_weights(d, w)
+    y, stats, tiles = ops.conv_forward(d, torch.zeros(0, 16, 16, 32, device="cuda"), None, wf)
+    assert y.shape == (0, 16, 16, 32)
+    dx0, _ = ops.conv_backward_data(d, torch.zeros(0, 16, 16, 32, device="cuda"), wd)
+    assert dx0.shape == (0, 16, 16, 32)
+    dw = ops.conv_backward_weight(d, torch.zeros(0, 16, 16, 32, device="cuda"), torch.zeros(0, 16, 16, 32, device="cuda"), None)
+    torch.cuda.synchronize()
+    assert dw.shape == w.shape and float(dw.abs().max()) == 0.0
