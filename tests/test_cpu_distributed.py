@@ -61,6 +61,18 @@ def test_bucket_allreduce_world2():
     assert ret[0][1] == [0, 1, 2, 3, 4] and ret[1][1] == [5, 6, 7, 8, 9]
 
 
+def test_bucket_allreduce_world4_ragged_shards():
+    """four ranks (the driver's N=4 point, rehearsed over gloo): same reduction, uneven shards of 10 items"""
+    world = 4
+    ranges = [(900, 1000), (300, 900), (0, 300)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_worker, (world, _free_port(), ranges, ret), world, seconds=120)
+    assert all(ret[r][0] for r in range(world))
+    shards = [ret[r][1] for r in range(world)]
+    assert shards == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]] and sum(shards, []) == list(range(10))
+
+
 def test_single_process_is_a_noop():
     from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer, env_world, shard_indices
     red = BucketAllReducer()
