@@ -92,6 +92,42 @@ def cpu_baseline(size, batch, steps):
                       f"torch.set_num_threads({cores})"}
 
 
+def alt_f32x3(args, dev):
+    """Secondary figure of the default N=1 run, NOT the headline: the same training step with compute_dtype="f32x3"
+    -- fp32 tensors and fp32 accumulation, every conv product formed from six bf16 MFMAs over an exact 3-way split of
+    both fp32 operands (dropped terms <= 2^-24 |ab|; same parity gates as the fp32-MFMA path, tests/test_gpu_ops.py,
+    tests/test_gpu_unet.py).  `value` of the JSON line is always measured on the true fp32 MFMA."""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    torch.manual_seed(0)
+    lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
+                    num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
+                    mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
+                    augment=False, precision="f32x3").to(dev).train()
+    (opt,), _ = lit.configure_optimizers()
+    nb = 4
+    data = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = lit.training_step({"image": data[i % nb], "index": None}, i)
+        loss.backward()
+        opt.step()
+        return loss
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(args.batch * args.steps / dt, 2), "unit": "images/sec",
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "final_loss": round(float(loss.item()), 5),
+            "note": "fp32 storage/accumulation, conv products from 6 bf16 MFMAs over an exact 3-way operand split; "
+                    "opt-in (--dtype f32x3), not the headline"}
+
+
 def extra_workload(args):
     """secondary workloads of BASELINE.json (not the headline metric): one JSON line each."""
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
@@ -328,38 +364,9 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
                            "traffic": None}
     if world == 1 and args.dtype == "f32" and not args.no_alt:
-        # Secondary figure, NOT the headline: the same step with compute_dtype="f32x3" -- fp32 tensors and fp32
-        # accumulation, every conv product formed from six bf16 MFMAs over an exact 3-way split of both fp32
-        # operands (dropped terms <= 2^-24 |ab|; same parity gates as the fp32 MFMA path, tests/test_gpu_ops.py,
-        # tests/test_gpu_unet.py).  `value` above is measured on the true fp32 MFMA.
-        del lit, opt, data
+        del lit, opt, data, step  # free the fp32 run's 2 GB workspace before building the second model
         torch.cuda.empty_cache()
-        torch.manual_seed(0)
-        lit2 = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
-                         num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
-                         mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
-                         augment=False, precision="f32x3").to(dev).train()
-        (opt2,), _ = lit2.configure_optimizers()
-        data2 = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
-
-        def step2(i):
-            opt2.zero_grad(set_to_none=True)
-            l2 = lit2.training_step({"image": data2[i % nb], "index": None}, i)
-            l2.backward()
-            opt2.step()
-            return l2
-        for i in range(args.warmup):
-            l2 = step2(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            l2 = step2(args.warmup + i)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        out["alt_f32x3"] = {"value": round(args.batch * args.steps / dt2, 2), "unit": "images/sec",
-                            "ms_per_step": round(1e3 * dt2 / args.steps, 3), "final_loss": round(float(l2.item()), 5),
-                            "note": "fp32 storage/accumulation, conv products from 6 bf16 MFMAs over an exact 3-way "
-                                    "operand split; opt-in (--dtype f32x3), not the headline"}
+        out["alt_f32x3"] = alt_f32x3(args, dev)
         log(f"alt f32x3: {out['alt_f32x3']['value']} images/s")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.cpu_steps)
