@@ -281,3 +281,23 @@ def test_cli_smoke(tmp_path):
     r = CliRunner().invoke(cli, ["train", "modify", "--config_path", str(swap), "--checkpoint_path", str(last),
                                  "--max_steps", "2"])
     assert r.exit_code == 0, r.output + str(r.exception)
+    # d3f balance on real image files: PIL reader -> training -> scoring -> class list
+    from PIL import Image
+    (tmp_path / "imgs").mkdir()
+    rng = np.random.default_rng(0)
+    names = []
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(tmp_path / "imgs" / f"{i}.png")
+        names.append(f"imgs/{i}.png")
+    (tmp_path / "images.txt").write_text("\n".join(names) + "\n")
+    bal = tmp_path / "balance.yml"
+    bal.write_text(yaml.safe_dump(dict(batch_size=3, learning_rate=0.01, max_epochs=1, num_workers=0,
+                                       encoder_name="resnet34", ratio_of_noise=0.7, number_of_classes=3,
+                                       mean=[128, 128, 128], std=[128, 128, 128],
+                                       default_root_dir=str(tmp_path / "logs3"))))
+    out_list = tmp_path / "classes.txt"
+    r = CliRunner().invoke(cli, ["balance", "--config", str(bal), "--input_list", str(tmp_path / "images.txt"),
+                                 "--output_list", str(out_list)])
+    assert r.exit_code == 0, r.output + str(r.exception)
+    rows = [l.split("\t") for l in out_list.read_text().strip().splitlines()]
+    assert [r_[0] for r_ in rows] == names and {int(r_[1]) for r_ in rows} <= {0, 1, 2}
