@@ -28,9 +28,11 @@ def _dot(a, b):
     return (a.double() * b.double()).sum().item()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x3"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[str(s) for s in SHAPES])
-def test_adjoint_identities(shape):
+def test_adjoint_identities(shape, mode):
     from denoising_diffusion_deep_fake_amd import ops
+    DT = ops.F32 if mode == "f32" else ops.F32X3
     B, H, W, C0, C1, Co, k, s, pd, up = shape
     g = torch.Generator(device="cuda").manual_seed(0)
     h0, w0 = (H // 2, W // 2) if up else (H, W)
@@ -38,11 +40,11 @@ def test_adjoint_identities(shape):
     x1 = torch.randn(B, H, W, C1, device="cuda", generator=g) if C1 else None
     w = torch.randn(Co, C0 + C1, k, k, device="cuda", generator=g) / ((C0 + C1) * k * k) ** 0.5
     d = ops.make_desc(B, H, W, C0, C1, Co, k, s, pd, up)
-    wf, wd = ops.pack_weights(d, w)
-    y, _, _ = ops.conv_forward(d, x0, x1, wf, splitk=True)
+    wf, wd = ops.pack_weights(d, w, DT)
+    y, _, _ = ops.conv_forward(d, x0, x1, wf, DT, splitk=True)
     dy = torch.randn(y.shape, device="cuda", generator=g)
-    dx0, dx1 = ops.conv_backward_data(d, dy, wd, splitk=True)
-    dw = ops.conv_backward_weight(d, dy, x0, x1)
+    dx0, dx1 = ops.conv_backward_data(d, dy, wd, DT, splitk=True)
+    dw = ops.conv_backward_weight(d, dy, x0, x1, DT)
     lhs = _dot(y, dy)
     # <x, dX>: the up-sampled source enters through its nearest x2 expansion = sum over the 2x2 block of dX0
     dx0_low = ops.upsample2x_backward(dx0) if up else dx0
@@ -53,10 +55,10 @@ def test_adjoint_identities(shape):
     assert abs(lhs - via_w) < 2e-5 * scale, (lhs, via_w)
     # linearity of the forward kernel
     x0b = torch.randn(x0.shape, device="cuda", generator=g)
-    yb, _, _ = ops.conv_forward(d, x0b, x1, wf, splitk=True)
-    ysum, _, _ = ops.conv_forward(d, x0 + x0b, x1, wf, splitk=True)
+    yb, _, _ = ops.conv_forward(d, x0b, x1, wf, DT, splitk=True)
+    ysum, _, _ = ops.conv_forward(d, x0 + x0b, x1, wf, DT, splitk=True)
     if C1:
-        y_skip_only, _, _ = ops.conv_forward(d, torch.zeros_like(x0), x1, wf, splitk=True)
+        y_skip_only, _, _ = ops.conv_forward(d, torch.zeros_like(x0), x1, wf, DT, splitk=True)
         ref = y + yb - y_skip_only
     else:
         ref = y + yb

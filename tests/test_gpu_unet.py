@@ -298,3 +298,30 @@ def test_f32x3_contraction_mode():
         assert _within(errs[dt][1], e_cpu[1], CAP_GRAD_FLAT, 2e-5, NOISE_GRAD), (dt, errs[dt], e_cpu)
     # and the split mode is not measurably less accurate than the fp32 MFMA in the forward pass
     assert errs["f32x3"][0] < 1.5 * errs["f32"][0] + 1e-7
+
+
+def test_baseline_config_128_bs16():
+    """BASELINE.json configs[1] shape (128x128, bs 16, fp32): forward and flat gradient against the float64 oracle."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd import Unet
+    torch.manual_seed(11)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    x = oracle.synthetic_face_crops(16, 128, seed=5)
+    ref64 = copy.deepcopy(ref).double().train()
+    y64 = ref64(x.double())
+    y64.square().mean().backward()
+    g64 = torch.cat([p.grad.reshape(-1) for p in ref64.parameters()])
+    y_ref = ref(x)
+    y_ref.square().mean().backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    net = Unet("resnet34", None, 3, 3, None)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().train()
+    y = net(x.cuda())
+    y.square().mean().backward()
+    e_fwd, e_fwd_cpu = rel_l2(y, y64), rel_l2(y_ref, y64)
+    e_g, e_g_cpu = rel_l2(net.flat_grads, g64), rel_l2(g_ref, g64)
+    print("128x128 bs16 rel-L2 vs float64: forward hip %.2e cpu %.2e | gradient hip %.2e cpu %.2e"
+          % (e_fwd, e_fwd_cpu, e_g, e_g_cpu))
+    assert _within(e_fwd, e_fwd_cpu, CAP_FWD, 2e-6)
+    assert _within(e_g, e_g_cpu, CAP_GRAD_FLAT, 2e-5, NOISE_GRAD)
