@@ -353,8 +353,13 @@ def main():
             # PMC counters cannot be read from inside this process: per-launch HBM bytes of the same launches,
             # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        busy = None
+        upath = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
+        if os.path.exists(upath) and args.dtype == "f32" and args.size == 256 and args.batch == 16:
+            # same source as `traffic`: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of this kernel over a training step
+            busy = next((k["mfma_pipe_busy"] for k in json.load(open(upath))["kernels"] if k["kernel"] == "conv_igemm"), None)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "mfma_pipe_busy_pmc": busy,
                            "kernel": "conv_igemm_kernel (forward launches; its data-gradient launches overlap "
                                      "the weight-gradient kernel on a second stream)",
                            "launches": int(n[0]), "sampled_steps": f"{sampled} of {args.steps} timed steps",
