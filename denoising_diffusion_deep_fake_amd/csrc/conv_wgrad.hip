@@ -66,8 +66,9 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
-  static_assert(!X3 || (sizeof(T) == 4 && BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1),
-                "x3 weight gradient: fp32 operands, 64x64 tile");
+  static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
+  // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
+  constexpr int NPL = sizeof(T) == 4 ? 3 : 1;
   constexpr int TM = BMW / WGM, TN = BNW / WGN, FM = TM / 32, FN = TN / 32;
   constexpr int LY = BMW + 4, LX = BNW + 4;    // LDS row strides (floats), 16-B aligned rows
   constexpr int VY = BMW / VE, VX = BNW / VE;  // 16-byte global vectors per row
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   static_assert(WGM * WGN * KSPLIT == 4, "4 waves");
   constexpr int RED = (KSPLIT > 1) ? KSPLIT * 32 * 32 : 1;
   // x3: per operand 3 planes x 2 subtiles x [32 pixels][32 channels] bf16
-  constexpr int X3_SUB = KP * 64, X3_PLANE = 2 * X3_SUB, X3_OP = 3 * X3_PLANE;  // bytes
+  constexpr int X3_SUB = KP * 64, X3_PLANE = 2 * X3_SUB, X3_OP = (sizeof(T) == 4 ? 3 : 1) * X3_PLANE;  // bytes
   constexpr int F32_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
   constexpr int LDS_FLOATS = X3 ? 2 * X3_OP / 4 : F32_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -207,8 +208,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   if constexpr (X3) {
     typedef short v4s __attribute__((ext_vector_type(4)));
     unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
-    // staging: this thread's 4 channels of one pixel -> 8 bytes per plane
-    const int ywoff = (ycv >> 3) * X3_SUB + (ycv & 7) * 8, xwoff = (xcv >> 3) * X3_SUB + (xcv & 7) * 8;
+    // staging: this thread's VE channels of one pixel -> 8 bytes per plane (fp32) / 16 bytes (bf16)
+    constexpr int VPS = 32 / VE;  // 16-byte global vectors per 32-channel subtile
+    const int ywoff = (ycv / VPS) * X3_SUB + (ycv % VPS) * (VE * 2), xwoff = (xcv / VPS) * X3_SUB + (xcv % VPS) * (VE * 2);
     // fragment gather: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies row q, channels 4p..
     const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
     const int rd_lane = ((grp >> 1) * 8 + q) * 64 + ((grp & 1) * 16 + 4 * pq) * 2;  // + s*16*64 + h*4*64
@@ -227,41 +229,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int i = 0; i < NVY; ++i) {
         const int row = yrow0 + i * YRS;
         if (row < KP) {
-          uint2 h, m, l;
-          wg_split3x4(ry[i], h, m, l);
           unsigned char* d = lb + row * 64 + ywoff;
-          *reinterpret_cast<uint2*>(d) = h;
-          *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
-          *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+          if constexpr (sizeof(T) == 4) {
+            uint2 h, m, l;
+            wg_split3x4(ry[i], h, m, l);
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+          } else {
+            *reinterpret_cast<uint4*>(d) = ry[i];
+          }
         }
       }
 #pragma unroll
       for (int i = 0; i < NVX; ++i) {
         const int row = xrow0 + i * XRS;
         if (row < KP) {
-          uint2 h, m, l;
-          wg_split3x4(rx[i], h, m, l);
           unsigned char* d = lb + X3_OP + row * 64 + xwoff;
-          *reinterpret_cast<uint2*>(d) = h;
-          *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
-          *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+          if constexpr (sizeof(T) == 4) {
+            uint2 h, m, l;
+            wg_split3x4(rx[i], h, m, l);
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + X3_PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = l;
+          } else {
+            *reinterpret_cast<uint4*>(d) = rx[i];
+          }
         }
       }
       __syncthreads();
       if (ch + 1 < chunk_end) load_chunk(ch + 1);
 #pragma unroll
       for (int s = 0; s < KP / 16; ++s) {
-        uint4 a[3], b[3];
+        uint4 a[NPL], b[NPL];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           a[pl] = frag(ya, pl, s);
           b[pl] = frag(xa, pl, s);
         }
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
+        if constexpr (NPL == 3) {
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // small terms first
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a[PA[t]]),
-                                                              *reinterpret_cast<const bf16x8*>(&b[PB[t]]), acc[0][0], 0, 0, 0);
+          for (int t = 0; t < 6; ++t)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a[PA[t]]),
+                                                                *reinterpret_cast<const bf16x8*>(&b[PB[t]]), acc[0][0], 0, 0, 0);
+        } else {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a[0]),
+                                                              *reinterpret_cast<const bf16x8*>(&b[0]), acc[0][0], 0, 0, 0);
+        }
       }
       __syncthreads();
     }
@@ -424,11 +439,10 @@ template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, d
   if (bm == 128) {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1, false>), grid, block, 0, stream, p);
   } else if (bm == 64) {
-    if constexpr (sizeof(T) == 4) {
-      if (x3) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
-        return;
-      }
+    static const bool widen = getenv("D3F_BF16_WGRAD_F32") != nullptr;  // bf16 storage: old widening form (tuning knob)
+    if (x3 || (sizeof(T) == 2 && !widen)) {
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
+      return;
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, 0, stream, p);
   } else {
