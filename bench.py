@@ -3,8 +3,10 @@
 U-Net forward -> (MSE + 1-SSIM)/2 -> backward -> Adam) on synthetic 256x256 face crops, bs=16 per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-one rank per GPU over RCCL.)  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU over RCCL), or -- when WORLD_SIZE is not set -- this process starts exactly that command as a
+CHILD (before any HIP call of its own) and relays rank 0's JSON line and the exit code.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
 import json
@@ -26,17 +28,17 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame-size", type=int, default=448, help="--workload predict: frame height = width")
-    ap.add_argument("--no-alt", action="store_true", help="skip the secondary f32x3 measurement of the default run")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary f32x3 / bf16 measurements of the default run")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the contraction kernels with HIP events in the timed region")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict"],
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
@@ -92,18 +94,25 @@ def cpu_baseline(size, batch, steps):
                       f"torch.set_num_threads({cores})"}
 
 
-def alt_f32x3(args, dev):
-    """Secondary figure of the default N=1 run, NOT the headline: the same training step with compute_dtype="f32x3"
-    -- fp32 tensors and fp32 accumulation, every conv product formed from six bf16 MFMAs over an exact 3-way split of
-    both fp32 operands (dropped terms <= 2^-24 |ab|; same parity gates as the fp32-MFMA path, tests/test_gpu_ops.py,
-    tests/test_gpu_unet.py).  `value` of the JSON line is always measured on the true fp32 MFMA."""
+ALT_NOTES = {
+    "f32x3": "fp32 storage/accumulation, conv products from 6 bf16 MFMAs over an exact 3-way operand split; "
+             "opt-in (--dtype f32x3), same parity gates as the fp32-MFMA path; not the headline",
+    "bf16": "bf16 activations / packed weights on the bf16 MFMA, fp32 accumulation, statistics and master weights "
+            "(BASELINE.json config 2's dtype); opt-in (--dtype bf16), gated by tests/test_gpu_bf16.py; not the headline",
+}
+
+
+def alt_dtype(args, dev, dtype):
+    """Secondary figures of the default N=1 run, NOT the headline: the same training step with
+    compute_dtype="f32x3" (fp32 tensors and fp32 accumulation, every conv product formed from six bf16 MFMAs over an
+    exact 3-way split of both fp32 operands) or "bf16".  `value` of the JSON line is always the true fp32 MFMA."""
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
     from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
     torch.manual_seed(0)
     lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
                     num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
                     mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
-                    augment=False, precision="f32x3").to(dev).train()
+                    augment=False, precision=dtype).to(dev).train()
     (opt,), _ = lit.configure_optimizers()
     nb = 4
     data = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
@@ -124,8 +133,7 @@ def alt_f32x3(args, dev):
     dt = time.perf_counter() - t0
     return {"value": round(args.batch * args.steps / dt, 2), "unit": "images/sec",
             "ms_per_step": round(1e3 * dt / args.steps, 3), "final_loss": round(float(loss.item()), 5),
-            "note": "fp32 storage/accumulation, conv products from 6 bf16 MFMAs over an exact 3-way operand split; "
-                    "opt-in (--dtype f32x3), not the headline"}
+            "note": ALT_NOTES[dtype]}
 
 
 def extra_workload(args):
@@ -184,7 +192,8 @@ def extra_workload(args):
         lit = LitModule(mode="denoise", batch_size=bs, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=50,
                         cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
                         noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
-                        std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype).to(dev).train()
+                        std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype,
+                        augment=False).to(dev).train()
         opts, _ = lit.configure_optimizers()
         batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i, device=dev), "index": None}
                  for i, k in enumerate("ab")}
@@ -223,10 +232,49 @@ def extra_workload(args):
     print(json.dumps(res), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+    (never os.exec*), before this process has made any HIP call, and hand back its exit code; rank 0 of the child job
+    prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("no launcher around --gpus %d: starting %s" % (args.gpus, " ".join(cmd[1:8])))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def pmc_from_file(name, key, args):
+    """PMC counters cannot be read from inside this process.  Figures collected by the builder with rocprofv3 (separate
+    --pmc passes, gfx950 corrections; profiles/tools/collect_*.sh) are attached WITH their provenance, and only for the
+    configuration they were collected on -- they are not measurements of this run."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not (os.path.exists(path) and args.dtype == "f32" and args.size == 256 and args.batch == 16):
+        return None, None
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    src = {"file": "profiles/" + name, "collected_at_git_head": d.get("git_head"), "date": d.get("date"),
+           "note": "builder's rocprofv3 --pmc run of the same command, NOT measured by this run"}
+    return key(d), src
+
+
 def main():
     args = parse()
     if args.workload != "denoiser":
         return extra_workload(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # before anything in this process touches the GPU
     from denoising_diffusion_deep_fake_amd import _lib
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
     from denoising_diffusion_deep_fake_amd.distributed import DataParallel, init_process_group
@@ -236,7 +284,7 @@ def main():
 
     world, rank, local = init_process_group()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("D3F_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (gloo)
         local = int(os.environ["D3F_FORCE_DEVICE"])
     torch.cuda.set_device(local)
@@ -273,35 +321,36 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     use_events = not args.no_kernel_events
+    # An event pair costs ~8 us of stream time (its marker packets drain the queue), so only the launches of the
+    # roofline kernel -- conv_igemm_kernel: 47 forward + 46 data-gradient launches per step -- are bracketed, and only
+    # on every EVERY-th timed step (>= 5 sampled steps whenever K >= 5).  The weight-gradient kernels are timed in a
+    # separate pass after the timed region.
+    EVERY = max(1, min(8, args.steps // 5))
     fence()
     if use_events:
-        # An event pair costs ~8 us of stream time (the marker packets drain the queue), so the timed region
-        # brackets only the roofline kernel's launches (forward conv_igemm), on every EVERY-th step; the
-        # gradient kernels are timed in a separate pass after it.
-        _lib.check(L.d3f_profile_enable(args.steps * 64 + 64))
-    EVERY = 4
+        _lib.check(L.d3f_profile_enable(((args.steps + EVERY - 1) // EVERY) * 128 + 64))
     t0 = time.perf_counter()
     for i in range(args.steps):
         if use_events:
-            L.d3f_profile_classes(1 if i % EVERY == 0 else 0)
+            L.d3f_profile_classes(3 if i % EVERY == 0 else 0)
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     ms, n, fl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+    sampled = (args.steps + EVERY - 1) // EVERY
+    diag = min(args.steps, 5)
     if use_events:
         L.d3f_profile_collect(ms, n, fl)
-        # diagnostic pass outside the timed region: the data- and weight-gradient launches
-        diag = min(args.steps, 5)
-        _lib.check(L.d3f_profile_classes(6))
-        _lib.check(L.d3f_profile_enable(diag * 128 + 64))
+        # diagnostic pass outside the timed region: the weight-gradient launches (side stream)
+        _lib.check(L.d3f_profile_classes(4))
+        _lib.check(L.d3f_profile_enable(diag * 64 + 64))
         for i in range(diag):
             loss = step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ms2, n2, fl2 = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
         L.d3f_profile_collect(ms2, n2, fl2)
-        for k in (1, 2):
-            ms[k], n[k], fl[k] = ms2[k], n2[k], fl2[k]
+        ms[2], n[2], fl[2] = ms2[2], n2[2], fl2[2]
         L.d3f_profile_classes(7)
         L.d3f_profile_enable(0)
     lossv = float(loss.item())
@@ -319,6 +368,8 @@ def main():
     images = args.batch * args.steps * world
     fwd_fl, bwd_fl = lit.model.conv_flops(args.batch, args.size, args.size, dev)
     step_flops = fwd_fl + bwd_fl
+    peak = PEAK_TFLOPS[args.dtype]
+    whole = step_flops / (dt / args.steps) / 1e12
     out = {
         "metric": "training images/sec (256x256 U-Net, bs=16/GPU)",
         "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -330,49 +381,48 @@ def main():
                    "image_size": args.size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "final_loss": round(lossv, 5),
                    "conv_gflop_per_image_step": round(step_flops / args.batch / 1e9, 3),
-                   "whole_step_conv_tflops": round(step_flops / (dt / args.steps) / 1e12, 2)},
+                   "whole_step_conv_tflops": round(whole, 2),
+                   "whole_step_frac_of_peak": round(whole / peak, 4)},
     }
-    peak = PEAK_TFLOPS[args.dtype]
-    if use_events and n[0] > 0:
-        names = ["conv_igemm_kernel (forward)", "conv_igemm_kernel (data gradient)", "conv_wgrad_kernel"]
-        sampled = (args.steps + EVERY - 1) // EVERY
-        nsteps = [sampled, min(args.steps, 5), min(args.steps, 5)]
+    if use_events and n[0] > 0 and n[1] > 0:
+        names = ["conv_igemm_kernel (forward launches)", "conv_igemm_kernel (data-gradient launches)",
+                 "conv_wgrad_* (weight-gradient launches)"]
+        nsteps = [sampled, sampled, diag]
         per = [{"kernel": names[k], "launches": int(n[k]), "avg_us": round(1e3 * ms[k] / max(n[k], 1), 2),
                 "tflops": round(fl[k] / max(ms[k], 1e-9) / 1e9, 2),
                 "ms_per_step": round(ms[k] / nsteps[k], 3)} for k in range(3)]
-        # The backward pass runs data-gradient and weight-gradient kernels CONCURRENTLY (two streams), so
-        # their individual durations overlap and over-state kernel time; the forward launches of the same
-        # conv_igemm kernel run with exclusive occupancy and are what the roofline figure is taken on.
-        ach = fl[0] / ms[0] / 1e9
-        for k in (1, 2):
-            per[k]["concurrent"] = True
-            per[k]["timed_region"] = False  # measured in a separate pass right after the timed steps
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.dtype == "f32" and args.size == 256 and args.batch == 16:
-            # PMC counters cannot be read from inside this process: per-launch HBM bytes of the same launches,
-            # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        busy = None
-        upath = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
-        if os.path.exists(upath) and args.dtype == "f32" and args.size == 256 and args.batch == 16:
-            # same source as `traffic`: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of this kernel over a training step
-            busy = next((k["mfma_pipe_busy"] for k in json.load(open(upath))["kernels"] if k["kernel"] == "conv_igemm"), None)
+        # the data-gradient launches share the machine with the weight-gradient kernels of the second stream, so
+        # their durations include that contention -- exactly what rocprofv3's kernel trace of this command reports
+        per[1]["concurrent_with_weight_gradient_stream"] = True
+        per[2]["concurrent_with_data_gradient_stream"] = True
+        per[2]["timed_region"] = False  # measured in a separate pass right after the timed steps
+        # ROOFLINE FIGURE: every launch of the dominant kernel (forward AND data gradient) on the sampled timed steps
+        t_all, f_all, n_all = ms[0] + ms[1], fl[0] + fl[1], n[0] + n[1]
+        ach = f_all / t_all / 1e9
+        traffic, tsrc = pmc_from_file("r02_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
+        busy, bsrc = pmc_from_file("r02_mfma_util.json", lambda d: next(
+            (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic, "mfma_pipe_busy_pmc": busy,
-                           "kernel": "conv_igemm_kernel (forward launches; its data-gradient launches overlap "
-                                     "the weight-gradient kernel on a second stream)",
-                           "launches": int(n[0]), "sampled_steps": f"{sampled} of {args.steps} timed steps",
-                           "avg_launch_us": round(1e3 * ms[0] / n[0], 2),
-                           "flop_per_launch": round(fl[0] / n[0], 1), "per_kernel": per}
+                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "kernel": "conv_igemm_kernel, ALL launches (47 forward + 46 data-gradient per step)",
+                           "launches": int(n_all), "sampled_steps": f"{sampled} of {args.steps} timed steps",
+                           "avg_launch_us": round(1e3 * t_all / n_all, 2),
+                           "flop_per_launch": round(f_all / n_all, 1),
+                           "ms_per_step": round(t_all / sampled, 3),
+                           "per_kernel": per}
+        if tsrc is not None:
+            out["roofline"]["traffic_source"] = tsrc
+        if busy is not None:
+            out["roofline"]["pmc_from_file"] = dict(bsrc, mfma_pipe_busy=busy)
     else:
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
                            "traffic": None}
     if world == 1 and args.dtype == "f32" and not args.no_alt:
-        del lit, opt, data, step  # free the fp32 run's 2 GB workspace before building the second model
-        torch.cuda.empty_cache()
-        out["alt_f32x3"] = alt_f32x3(args, dev)
-        log(f"alt f32x3: {out['alt_f32x3']['value']} images/s")
+        del lit, opt, data, step  # free the fp32 run's 2 GB workspace before building the next model
+        for alt in ("f32x3", "bf16"):
+            torch.cuda.empty_cache()
+            out["alt_" + alt] = alt_dtype(args, dev, alt)
+            log(f"alt {alt}: {out['alt_' + alt]['value']} images/s")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.cpu_steps)
     print(json.dumps(out), flush=True)

@@ -56,7 +56,9 @@ class LitModule(LightningModule):
             m = [v / 255.0 if max(mean) > 1 else v for v in mean]
             s = [v / 255.0 if max(std) > 1 else v for v in std]
             dataset = ImageDataset(path, transform=NormalizeToTensor(m, s))
-        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=p.get("num_workers", 0), shuffle=shuffle)
+        workers = p.get("num_workers", 0)
+        extra = dict(multiprocessing_context="spawn", persistent_workers=True) if workers > 0 else {}  # never fork after HIP init
+        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=workers, shuffle=shuffle, **extra)
 
     def configure_optimizers(self):
         p = self.hparams

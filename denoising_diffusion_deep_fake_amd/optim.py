@@ -59,22 +59,72 @@ class FusedAdam(torch.optim.Optimizer):
         m.mark_params_changed()
         return loss
 
+    # ---- checkpoints: torch.optim.Adam's own format, both ways --------------------------------------------------
+    # A Lightning checkpoint written by the reference (d3f/train_deep_fake/start_training.py:19-23 resumes from one)
+    # stores optimizer_states[i] = torch.optim.Adam.state_dict(): {"state": {k: {"step", "exp_avg", "exp_avg_sq"}},
+    # "param_groups": [...]}, parameters numbered in model.parameters() order -- the order of the flat buffer.
+    def _flat_state(self):
+        flat = self.module.flat_params
+        if flat is None:
+            self.module.prepare()
+            flat = self.module.flat_params
+        if self.exp_avg is None or self.exp_avg.device != flat.device:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+        return flat
+
     def state_dict(self):
+        """per-parameter torch.optim.Adam state (CPU copies), so that torch.optim.Adam -- i.e. the reference --
+        can load what this optimiser saved"""
         sd = super().state_dict()
-        sd["d3f_flat"] = {"step": self._step,
-                          "exp_avg": None if self.exp_avg is None else self.exp_avg.cpu(),
-                          "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.cpu()}
+        state = {}
+        if self._step > 0 and self.exp_avg is not None:
+            off = 0
+            for i, p in enumerate(self.module._param_list):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self._step)),
+                            "exp_avg": self.exp_avg[off:off + n].reshape(p.shape).cpu(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].reshape(p.shape).cpu()}
+                off += n
+        sd["state"] = state
         return sd
 
     def load_state_dict(self, sd):
+        """accepts torch.optim.Adam's per-parameter state (a reference checkpoint) and gathers it into the flat
+        moments; also the round-1 private `d3f_flat` blob.  An optimizer state that names parameters but carries no
+        moments for some of them is refused rather than silently zeroed."""
         sd = dict(sd)
-        flat = sd.pop("d3f_flat", None)
-        super().load_state_dict(sd)
-        if flat is not None:
-            self._step = flat["step"]
-            dev = self.module.flat_params.device if self.module.flat_params is not None else "cuda"
-            self.exp_avg = None if flat["exp_avg"] is None else flat["exp_avg"].to(dev)
-            self.exp_avg_sq = None if flat["exp_avg_sq"] is None else flat["exp_avg_sq"].to(dev)
+        legacy = sd.pop("d3f_flat", None)
+        state = sd.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": sd["param_groups"]})
+        params = self.module._param_list
+        if state:
+            if len(state) != len(params):
+                raise ValueError(f"optimizer state covers {len(state)} parameters, the model has {len(params)}")
+            flat = self._flat_state()
+            steps = set()
+            off = 0
+            for i, p in enumerate(params):
+                st = state[i] if i in state else state[str(i)]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: exp_avg {tuple(st['exp_avg'].shape)} vs parameter "
+                                     f"{tuple(p.shape)}")
+                n = p.numel()
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1).to(flat.device, torch.float32))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(flat.device, torch.float32))
+                steps.add(int(float(st["step"])))
+                off += n
+            if len(steps) != 1:
+                raise ValueError(f"per-parameter Adam step counts differ ({sorted(steps)}): the flat update keeps one")
+            self._step = steps.pop()
+        elif legacy is not None and legacy.get("exp_avg") is not None:
+            flat = self._flat_state()
+            self.exp_avg.copy_(legacy["exp_avg"].to(flat.device))
+            self.exp_avg_sq.copy_(legacy["exp_avg_sq"].to(flat.device))
+            self._step = int(legacy["step"])
+        else:
+            self._step = 0
+            self.exp_avg = self.exp_avg_sq = None
 
 
 class EMA(torch.nn.Module):

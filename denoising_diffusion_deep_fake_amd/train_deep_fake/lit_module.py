@@ -4,12 +4,20 @@ Mirrors d3f/train_deep_fake/lit_module.py:30-300: two U-Nets (`model_a`, `model_
 optimisers alternated by `optimizer_idx`, `mode: "denoise"` (noisy real -> real) or `mode: "swap"`
 (EMA teacher of the OTHER domain renders a fake, the student denoises the noised fake back to the
 real image), and the single-frame inference entry `predict_fake`.  Same hyper-parameter keys as
-denoise_config.yml / swap_config.yml; extra optional keys: `synthetic`, `image_size`, `precision`.
+denoise_config.yml / swap_config.yml; extra optional keys: `synthetic`, `image_size`, `precision`, `augment`.
+
+Augmentation: the reference's `A.ShiftScaleRotate(shift_limit=0.2, scale_limit=0.1, rotate_limit=15, border_mode=0,
+p=0.7)` after `A.Normalize` (lit_module.py:99-111) runs on the GPU here -- per-sample Bernoulli(0.7), the same
+parameter ranges drawn with torch RNG, one HIP warp kernel (ops.affine_warp, K17) with a zero border in normalised
+units -- inside `training_step`, before the noise blend, so that 8 GPUs are not fed by 8 CPU warps.
+`augment: false` switches it off (benchmarks, parity tests).
 
 Reference quirks kept on purpose: the dataloaders receive `mean_x` as BOTH
 mean and std (lit_module.py:75-76); `predict_fake("a")` uses model_a with B's mean/std (:253-257);
 de-normalisation truncates with `.int()` BEFORE clamping (:293-294).
 """
+import math
+import zlib
 from datetime import timedelta
 
 import numpy as np
@@ -27,10 +35,46 @@ from ..trainer import LearningRateMonitor, ModelCheckpoint
 from ..unet import Unet
 
 
+class ShiftScaleRotate(nn.Module):
+    """albumentations.ShiftScaleRotate(shift_limit, scale_limit, rotate_limit, border_mode=0, p) on a normalised
+    NCHW batch on the HIP device: with probability p per sample, rotate by U(-rotate, rotate) degrees and scale by
+    U(1 - scale, 1 + scale) about the image centre, then shift by U(-shift, shift) x (width, height); bilinear,
+    constant-zero border; the other samples pass through untouched."""
+
+    def __init__(self, shift_limit=0.2, scale_limit=0.1, rotate_limit=15.0, p=0.7):
+        super().__init__()
+        self.shift_limit, self.scale_limit, self.rotate_limit, self.p = shift_limit, scale_limit, rotate_limit, p
+
+    @staticmethod
+    def theta(angle_deg, scale, dx, dy, height, width):
+        """[B, 2, 3] affine_grid matrices (output -> input, normalised coordinates, align_corners=False) of
+        cv2.warpAffine(img, M) with M = getRotationMatrix2D(centre, angle, scale) + (dx * width, dy * height):
+        about the centre x - c = (W / 2) u, so  in - c = R(-angle) / scale * ((out - c) - shift)."""
+        a = angle_deg * (math.pi / 180.0)
+        cos, sin = torch.cos(a) / scale, torch.sin(a) / scale
+        a11, a12, a21, a22 = cos, -sin * (height / width), sin * (width / height), cos
+        t1 = -2.0 * (a11 * dx + a12 * dy)
+        t2 = -2.0 * (a21 * dx + a22 * dy)
+        return torch.stack([torch.stack([a11, a12, t1], 1), torch.stack([a21, a22, t2], 1)], 1)
+
+    def draw(self, B, device):
+        u = lambda lim: (torch.rand(B, device=device) * 2 - 1) * lim  # noqa: E731
+        return {"apply": torch.rand(B, device=device) < self.p, "angle": u(self.rotate_limit),
+                "scale": 1.0 + u(self.scale_limit), "dx": u(self.shift_limit), "dy": u(self.shift_limit)}
+
+    @torch.no_grad()
+    def forward(self, x, draws=None):
+        d = self.draw(x.shape[0], x.device) if draws is None else draws
+        th = self.theta(d["angle"], d["scale"], d["dx"], d["dy"], x.shape[2], x.shape[3])
+        warped = ops.affine_warp(x, th)
+        return torch.where(d["apply"].reshape(-1, 1, 1, 1), warped, x)
+
+
 class LitModule(LightningModule):
     def __init__(self, **kwargs):
         super().__init__()
         self.save_hyperparameters()
+        self.augmentation = self.create_gpu_augmentation()
         self.model_a = self.create_model_instance()
         self.model_b = self.create_model_instance()
         self.ema_model_a = self.create_ema_model(self.model_a)
@@ -61,24 +105,33 @@ class LitModule(LightningModule):
 
     def train_dataloader(self):
         p = self.hparams
-        dataloader_a = self.create_dataloader(p.get("data_path_a"), p.mean_a, p.mean_a)
-        dataloader_b = self.create_dataloader(p.get("data_path_b"), p.mean_b, p.mean_b)
+        dataloader_a = self.create_dataloader(p.get("data_path_a"), p.mean_a, p.mean_a, domain="a")
+        dataloader_b = self.create_dataloader(p.get("data_path_b"), p.mean_b, p.mean_b, domain="b")
         return {"a": dataloader_a, "b": dataloader_b}
 
-    def create_dataloader(self, path, mean, std):
+    def create_dataloader(self, path, mean, std, domain=""):
         p = self.hparams
         if p.get("synthetic", False) or path is None:
-            dataset = SyntheticFaceDataset(p.get("synthetic_length", 8 * p.batch_size), p.get("image_size", 256),
-                                           seed=1234 + (hash(str(path)) % 1000))
+            # a stable, per-domain seed (str hashes are randomised per process; two None paths must still differ)
+            seed = 1234 + zlib.crc32(f"{domain}:{path}".encode()) % 1000
+            dataset = SyntheticFaceDataset(p.get("synthetic_length", 8 * p.batch_size), p.get("image_size", 256), seed=seed)
         else:
             dataset = ImageDataset(path, transform=self.create_augmentation_sequence(mean, std))
-        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=p.get("num_workers", 0),
-                          shuffle=True, drop_last=True)
+        workers = p.get("num_workers", 0)
+        # shuffle=True and the ragged last batch kept, as the reference (lit_module.py:90-95); workers are SPAWNED:
+        # forking a process that has initialised HIP is not safe
+        extra = dict(multiprocessing_context="spawn", persistent_workers=True) if workers > 0 else {}
+        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=workers, shuffle=True, **extra)
 
     def create_augmentation_sequence(self, mean, std):
-        # albumentations Normalize + ToTensorV2; the random ShiftScaleRotate(p=0.7) of the reference is
-        # augmentation noise outside the numerics contract
+        # host half of the reference's A.Compose: Normalize + ToTensorV2; its ShiftScaleRotate(p=0.7) runs on the
+        # GPU inside training_step (create_gpu_augmentation)
         return NormalizeToTensor(mean, std)
+
+    def create_gpu_augmentation(self):
+        if not self.hparams.get("augment", True):
+            return None
+        return ShiftScaleRotate(shift_limit=0.2, scale_limit=0.1, rotate_limit=15, p=0.7)
 
     def configure_optimizers(self):
         p = self.hparams
@@ -99,6 +152,13 @@ class LitModule(LightningModule):
     def training_step(self, batch, batch_idx, optimizer_idx):
         batch_a = batch["a"]["image"]
         batch_b = batch["b"]["image"]
+        if self.augmentation is not None:
+            # the reference augments in the dataset; each image of a combined batch is consumed by exactly one of the
+            # two optimiser steps (a by 0, b by 1), so warping the half a step uses is the same thing
+            if optimizer_idx == 0:
+                batch_a = self.augmentation(batch_a)
+            else:
+                batch_b = self.augmentation(batch_b)
         if optimizer_idx == 0:
             loss = self.training_step_for_one_model("a", batch_a, self.model_a, self.ema_model_b)
         if optimizer_idx == 1:

@@ -81,8 +81,11 @@ class LitModule(LightningModule):
             m = [v / 255.0 if max(mean) > 1 else v for v in mean]
             s = [v / 255.0 if max(std) > 1 else v for v in std]
             dataset = ImageDataset(path, transform=NormalizeToTensor(m, s))
-        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=p.get("num_workers", 0),
-                          shuffle=True, drop_last=True)
+        workers = p.get("num_workers", 0)
+        # shuffle=True, ragged last batch kept (d3f/train_denoiser/lit_module.py:78-86); workers are SPAWNED: forking
+        # a process that has initialised HIP is not safe
+        extra = dict(multiprocessing_context="spawn", persistent_workers=True) if workers > 0 else {}
+        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=workers, shuffle=True, **extra)
 
     def configure_optimizers(self):
         p = self.hparams

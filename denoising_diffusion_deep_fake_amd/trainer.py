@@ -12,11 +12,11 @@
     "optimizer_states", "lr_schedulers", "hyper_parameters"} under
     <default_root_dir>/version_N/checkpoints/
 Data parallel: one process per GPU (torch.distributed.run); gradients are all-reduced by
-distributed.DataParallel, overlapped with the backward pass.  `self.log` values stay on the device
+distributed.DataParallel, overlapped with the backward pass; every rank iterates ITS shard of each
+dataset (DistributedSampler, reshuffled per epoch) and draws its own noise stream (seed + rank).  `self.log` values stay on the device
 and are flushed to metrics.csv every `flush_every` steps (no per-step host sync).
 """
 import inspect
-import itertools
 import os
 import time
 from pathlib import Path
@@ -86,7 +86,8 @@ class ModelCheckpoint(Callback):
 
 
 class CombinedLoader:
-    """dict of loaders, mode "max_size_cycle": epoch length = the longest loader, shorter ones cycle."""
+    """dict of loaders, mode "max_size_cycle": epoch length = the longest loader; a shorter loader that runs out is
+    iterated AGAIN (a fresh pass: reshuffled, re-augmented), not replayed from a cache of its first pass."""
 
     def __init__(self, loaders):
         self.loaders = loaders
@@ -95,10 +96,40 @@ class CombinedLoader:
         return max(len(l) for l in self.loaders.values())
 
     def __iter__(self):
-        n = len(self)
-        its = {k: (iter(l) if len(l) == n else itertools.cycle(l)) for k, l in self.loaders.items()}
-        for _ in range(n):
-            yield {k: next(it) for k, it in its.items()}
+        its = {k: iter(l) for k, l in self.loaders.items()}
+        for _ in range(len(self)):
+            out = {}
+            for k, l in self.loaders.items():
+                try:
+                    out[k] = next(its[k])
+                except StopIteration:
+                    its[k] = iter(l)
+                    out[k] = next(its[k])
+            yield out
+
+
+def shard_loader(loader, world_size, rank, seed=0):
+    """the same DataLoader over this rank's shard: DistributedSampler(shuffle as the original loader did,
+    drop_last=False -> every rank sees ceil(N / world) samples, the tail padded by wrap-around as torch does)."""
+    from torch.utils.data import DataLoader, RandomSampler
+    from torch.utils.data.distributed import DistributedSampler
+    if world_size <= 1:
+        return loader
+    shuffle = isinstance(loader.sampler, RandomSampler)
+    sampler = DistributedSampler(loader.dataset, num_replicas=world_size, rank=rank, shuffle=shuffle, seed=seed,
+                                 drop_last=False)
+    kw = dict(batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
+              collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last)
+    if loader.num_workers > 0:
+        kw.update(multiprocessing_context=loader.multiprocessing_context, persistent_workers=loader.persistent_workers)
+    return DataLoader(loader.dataset, **kw)
+
+
+def _set_epoch(loader, epoch):
+    loaders = loader.loaders.values() if isinstance(loader, CombinedLoader) else [loader]
+    for l in loaders:
+        if hasattr(getattr(l, "sampler", None), "set_epoch"):
+            l.sampler.set_epoch(epoch)
 
 
 def _to_device(x, device):
@@ -131,6 +162,8 @@ class Trainer:
         self.log_dir = None
         self._metric_rows = []
         self.module = None
+        self._batches_done = None  # batches of the current epoch already trained (None between epochs)
+        self._skip_batches = 0     # mid-epoch resume: batches of the first epoch to pass over
 
     # ---- checkpoints ------------------------------------------------------------------------------
     def save_checkpoint(self, path):
@@ -139,6 +172,8 @@ class Trainer:
         ckpt = {
             "epoch": self.current_epoch,
             "global_step": self.global_step,
+            # None: saved at the end of an epoch; n: saved mid-epoch after n batches (train_time_interval)
+            "d3f_batches_done_in_epoch": self._batches_done,
             "pytorch-lightning_version": "1.9.5+d3f-hip",
             "state_dict": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
             "optimizer_states": [o.state_dict() for o in self.optimizers],
@@ -150,14 +185,27 @@ class Trainer:
         os.replace(tmp, path)
 
     def _restore(self, ckpt_path):
+        """Lightning's fit(ckpt_path=...): strict state_dict (a key / encoder mismatch must not resume from random
+        init silently), optimizer state in torch.optim.Adam's per-parameter form (reference-written checkpoints drop
+        in: FusedAdam gathers exp_avg / exp_avg_sq / step into its flat moments), schedulers, loop position."""
         ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
-        self.module.load_state_dict(ckpt["state_dict"], strict=False)
-        for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+        self.module.load_state_dict(ckpt["state_dict"], strict=True)
+        opt_states = ckpt.get("optimizer_states", [])
+        if opt_states and len(opt_states) != len(self.optimizers):
+            raise RuntimeError(f"checkpoint holds {len(opt_states)} optimizer states, the module configures "
+                               f"{len(self.optimizers)} optimizers")
+        for o, sd in zip(self.optimizers, opt_states):
             o.load_state_dict(sd)
         for s, sd in zip(self.lr_schedulers, ckpt.get("lr_schedulers", [])):
             s.load_state_dict(sd)
-        self.current_epoch = int(ckpt.get("epoch", 0)) + 1  # resume after the saved epoch
         self.global_step = int(ckpt.get("global_step", 0))
+        done = ckpt.get("d3f_batches_done_in_epoch")
+        if done is None:
+            self.current_epoch = int(ckpt.get("epoch", 0)) + 1  # saved at an epoch end: resume with the next epoch
+            self._skip_batches = 0
+        else:
+            self.current_epoch = int(ckpt.get("epoch", 0))      # saved mid-epoch: finish that epoch
+            self._skip_batches = int(done)
 
     # ---- logging ------------------------------------------------------------------------------------
     def _new_version_dir(self):
@@ -233,14 +281,29 @@ class Trainer:
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
 
         loaders = model.train_dataloader()
+        if self.world_size > 1:
+            # one shard per rank (otherwise every rank would train on all the data and the all-reduce would average
+            # N copies of nearly the same gradient) and one noise / augmentation stream per rank
+            seed = int(torch.initial_seed() % (1 << 31))
+            if isinstance(loaders, dict):
+                loaders = {k: shard_loader(l, self.world_size, self.global_rank, seed) for k, l in loaders.items()}
+            else:
+                loaders = shard_loader(loaders, self.world_size, self.global_rank, seed)
+            torch.manual_seed(seed + 1 + self.global_rank)
         loader = CombinedLoader(loaders) if isinstance(loaders, dict) else loaders
         for cb in callbacks:
             cb.on_fit_start(self, model)
         done = False
         while self.current_epoch < self.max_epochs and not done:
+            _set_epoch(loader, self.current_epoch)
+            skip, self._skip_batches = self._skip_batches, 0
+            self._batches_done = 0
             for batch_idx, batch in enumerate(loader):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
                     break
+                if batch_idx < skip:  # mid-epoch resume: these batches were trained before the checkpoint
+                    self._batches_done = batch_idx + 1
+                    continue
                 batch = _to_device(batch, device)
                 for oi, opt in enumerate(self.optimizers):
                     if len(self.optimizers) > 1:  # toggle_optimizer
@@ -256,6 +319,7 @@ class Trainer:
                     for ps in opt_params:
                         for p in ps:
                             p.requires_grad_(True)
+                self._batches_done = batch_idx + 1
                 for cb in callbacks:
                     cb.on_train_batch_end(self, model)
                 if self.global_step % max(self.log_every_n_steps, 1) == 0:
@@ -265,6 +329,7 @@ class Trainer:
                 if 0 < self.max_steps <= self.global_step:
                     done = True
                     break
+            self._batches_done = None
             for s in self.lr_schedulers:
                 s.step()
             self._run_validation(model, device)

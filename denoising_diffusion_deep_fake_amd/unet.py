@@ -106,6 +106,8 @@ class _Engine:
         if os.environ.get("D3F_POISON_WORKSPACE"):  # test hook: any read-before-write shows up as NaN
             self.workspace.fill_(0xFF)
         self.packed_version = None
+        self.serial = 0       # bumped by every forward that overwrites this workspace
+        self.in_use = False   # a recorded autograd graph still needs this workspace's activations
         self.fwd_flops = L.d3f_unet_forward_flops(self.h)
         self.bwd_flops = L.d3f_unet_backward_flops(self.h)
         self.nseg = L.d3f_unet_num_segments(self.h)
@@ -145,15 +147,43 @@ def param_table(encoder_name, in_channels, classes):
         L.d3f_unet_destroy(h)
 
 
+class _Lease:
+    """marks an engine's workspace as holding the activations of a live autograd graph; released by the backward
+    pass, or when the graph is dropped without one (the node, and with it this object, is destroyed)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        engine.in_use = True
+
+    def release(self):
+        if self.engine is not None:
+            self.engine.in_use = False
+            self.engine = None
+
+    __del__ = release
+
+
 class _UnetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, engine, *params):
         ctx.module, ctx.engine = module, engine
-        return module._run_forward(engine, x, training=True)
+        out = module._run_forward(engine, x, training=True)
+        ctx.serial = engine.serial
+        ctx.lease = _Lease(engine)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.module._run_backward(ctx.engine, grad_out)
+        eng = ctx.engine
+        if ctx.lease.engine is None:
+            raise D3FError("backward through the d3f Unet a second time: the activations were released by the first "
+                           "backward (retain_graph is not supported by the HIP path)")
+        if ctx.serial != eng.serial:
+            # cannot happen through Unet.forward (a leased workspace is never handed out again); guards direct
+            # _run_forward callers: silently using another forward's activations would give wrong gradients
+            raise D3FError("the workspace of this forward pass was overwritten by a later forward before backward ran")
+        ctx.module._run_backward(eng, grad_out)
+        ctx.lease.release()
         return (None, None, None) + (None,) * len(ctx.module._param_list)
 
 
@@ -303,12 +333,22 @@ class Unet(nn.Module):
         self._rt["grad_sync"] = fn
 
     # -- engine -------------------------------------------------------------------------------------
+    MAX_LIVE_GRAPHS = 4  # workspaces (2 GB each at bs 16, 256x256) per shape that may hold un-backwarded graphs
+
     def _engine(self, B, H, W, device):
+        """a plan + workspace for this shape whose activations no live autograd graph still needs.  smp.Unet allows
+        `crit(net(x1)) + crit(net(x2))` and a no_grad forward between forward and backward: each recorded forward
+        leases its workspace until its backward has run, and a further forward of the same shape gets another one."""
         key = (B, H, W, self.compute_dtype, device.index)
-        eng = self._rt["engines"].get(key)
-        if eng is None:
-            eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device)
-            self._rt["engines"][key] = eng
+        pool = self._rt["engines"].setdefault(key, [])
+        for eng in pool:
+            if not eng.in_use:
+                return eng
+        if len(pool) >= self.MAX_LIVE_GRAPHS:
+            raise D3FError(f"{len(pool)} forward passes of shape {(B, H, W)} are waiting for their backward pass; "
+                           f"run inference-only forwards under torch.no_grad()")
+        eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device)
+        pool.append(eng)
         return eng
 
     def _pack_if_needed(self, eng):
@@ -317,8 +357,9 @@ class Unet(nn.Module):
         # torch optimizers / load_state_dict show up on the parameters, not on the flat buffer
         ver = sum(p._version for p in rt["params"]) + rt["flat"]._version
         if rt["dirty"]:
-            for e in rt["engines"].values():
-                e.packed_version = None
+            for pool in rt["engines"].values():
+                for e in pool:
+                    e.packed_version = None
             rt["dirty"] = False
         if eng.packed_version != ver:
             check(_lib.lib().d3f_unet_pack_weights(eng.h, ptr(rt["flat"]), ptr(eng.workspace), stream_ptr()))
@@ -328,6 +369,7 @@ class Unet(nn.Module):
         rt = self._rt
         self._pack_if_needed(eng)
         out = torch.empty((x.shape[0], self.classes, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        eng.serial += 1
         check(_lib.lib().d3f_unet_forward(eng.h, ptr(rt["flat"]), ptr(rt["flat_bn"]), ptr(x), ptr(out),
                                           ptr(eng.workspace), 1 if training else 0, stream_ptr()))
         if training:

@@ -12,6 +12,8 @@ PINNED by tests/golden (generated from the reference's own functions):
     d3f/balance_training_images/lit_module.py:109-121, 139-142, 181-193 (tests/golden/balance.npz).
 PARITY UNPINNED (un-vendored `ema_pytorch`, restated from upstream defaults,
 SURVEY.md Appendix A.3): EMA.
+swap_step restates the reference's own orchestration (d3f/train_deep_fake/lit_module.py:183-206) on top of
+those parts.
 """
 import copy
 import math
@@ -154,3 +156,19 @@ def training_step(model, criterion, optimizer, image, noise, r):
     loss.backward()
     optimizer.step()
     return loss.detach(), pred.detach()
+
+
+def swap_step(real, real_model, fake_model, criterion, noise, r):
+    """d3f/train_deep_fake/lit_module.py:183-206 (`training_swap_step_for_one_model`) with the Gaussian noise and
+    the blend ratio supplied: the EMA teacher of the OTHER domain is updated, renders a fake from the real batch
+    under no_grad (the EMA wrapper is a registered sub-module of a training LightningModule, so its BatchNorm
+    layers use batch statistics), the fake is noised, and the student denoises it back to the real image.
+    Returns (loss, swap_difference, fake, prediction); loss carries the graph."""
+    fake_model.update()                                          # :185
+    with torch.no_grad():
+        fake = fake_model(real)                                  # :189
+        swap_diff = F.mse_loss(real, fake)                       # :191
+        noisy_fake = blend_with_given_noise(fake, noise, r)      # :193
+    real_prediction = real_model(noisy_fake)                     # :195
+    loss = criterion(real_prediction, real)                      # :197
+    return loss, swap_diff, fake, real_prediction

@@ -82,3 +82,42 @@ def test_single_process_is_a_noop():
     assert torch.equal(t, torch.ones(4)) and red.world_size == 1
     assert list(shard_indices(5, 1, 0)) == [0, 1, 2, 3, 4]
     assert list(shard_indices(3, 4, 3)) == []
+
+
+def _shard_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from torch.utils.data import DataLoader
+    from denoising_diffusion_deep_fake_amd.dataset.image_dataset import SyntheticFaceDataset
+    from denoising_diffusion_deep_fake_amd.distributed import init_process_group
+    from denoising_diffusion_deep_fake_amd.trainer import CombinedLoader, _set_epoch, shard_loader
+    init_process_group("gloo")
+    torch.manual_seed(7)  # the same global seed on every rank, as a user's seed_everything would leave it
+    base = {k: DataLoader(SyntheticFaceDataset(n, 32), batch_size=2, shuffle=True) for k, n in (("a", 10), ("b", 6))}
+    loader = CombinedLoader({k: shard_loader(l, world, rank, seed=3) for k, l in base.items()})
+    epochs = []
+    for epoch in range(2):
+        _set_epoch(loader, epoch)
+        seen = {"a": [], "b": []}
+        for batch in loader:
+            for k in seen:
+                seen[k] += [int(i) for i in batch[k]["index"]]
+        epochs.append(seen)
+    ret[rank] = epochs
+    dist.destroy_process_group()
+
+
+def test_trainer_shards_every_loader_per_rank():
+    """Trainer.fit under data parallelism: each rank iterates ITS shard of each dataset (DistributedSampler),
+    reshuffled per epoch; the ranks' shards are disjoint and together cover the dataset."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_shard_worker, (world, _free_port(), ret), world, seconds=90)
+    for epoch in range(2):
+        a0, a1 = ret[0][epoch]["a"], ret[1][epoch]["a"]
+        assert len(a0) == len(a1) == 5 and not set(a0) & set(a1) and sorted(a0 + a1) == list(range(10))
+        # the short loader ("b": 3 images per rank) is re-iterated to fill the epoch of the long one (3 batches)
+        b0, b1 = ret[0][epoch]["b"], ret[1][epoch]["b"]
+        assert not set(b0) & set(b1) and set(b0 + b1) == set(range(6))
+    assert ret[0][0]["a"] != ret[0][1]["a"], "set_epoch must reshuffle"

@@ -1,10 +1,15 @@
 """CPU: host-side mirror of the reference's Python surface (no kernels involved)."""
+from pathlib import Path
+
 import numpy as np
+import pytest
 import torch
 
 from denoising_diffusion_deep_fake_amd.dataset import ImageDataset, SyntheticFaceDataset
 from denoising_diffusion_deep_fake_amd.dataset.image_dataset import NormalizeToTensor
 from denoising_diffusion_deep_fake_amd.lightning import AttributeDict, LightningModule
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_image_dataset_contract(tmp_path):
@@ -110,3 +115,83 @@ def test_cli_has_the_reference_commands():
     from denoising_diffusion_deep_fake_amd.main import cli
     assert {"train", "denoise", "balance"} <= set(cli.commands)
     assert {"new", "resume", "modify"} <= set(cli.commands["train"].commands)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without a launcher: the parent builds the torch.distributed.run command for a CHILD process and
+    never initialises the GPU itself (an exec / HIP call in the parent is what the GPU box forbids)."""
+    import importlib.util
+    import subprocess
+    import sys
+    import types
+    spec = importlib.util.spec_from_file_location("d3f_bench", str(ROOT / "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+
+
+def test_shift_scale_rotate_theta_is_cv2_warp_affine():
+    """ShiftScaleRotate.theta must describe cv2.warpAffine(img, M) with M = getRotationMatrix2D(centre, angle, scale)
+    + (dx W, dy H) -- what albumentations.ShiftScaleRotate applies (d3f/train_deep_fake/lit_module.py:102-108).
+    Checked in pixel space: for every output pixel, M applied to the source position affine_grid names must give
+    the output pixel back."""
+    import math
+    import torch.nn.functional as F
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import ShiftScaleRotate
+    H, W = 24, 40
+    angle, scale = torch.tensor([11.0, -15.0, 0.0]), torch.tensor([1.08, 0.9, 1.0])
+    dx, dy = torch.tensor([0.2, -0.13, 0.0]), torch.tensor([-0.05, 0.2, 0.0])
+    th = ShiftScaleRotate.theta(angle, scale, dx, dy, H, W)
+    assert torch.allclose(th[2], torch.tensor([[1.0, 0, 0], [0, 1.0, 0]]), atol=1e-7)   # null draw = identity
+    grid = F.affine_grid(th, [3, 1, H, W], align_corners=False)        # [B, H, W, 2] normalised source positions
+    sx = ((grid[..., 0] + 1) * W - 1) / 2                                # -> source pixel coordinates
+    sy = ((grid[..., 1] + 1) * H - 1) / 2
+    cx, cy = (W - 1) / 2, (H - 1) / 2
+    for b in range(3):
+        a = math.radians(angle[b].item())
+        al, be = scale[b].item() * math.cos(a), scale[b].item() * math.sin(a)
+        m = torch.tensor([[al, be, (1 - al) * cx - be * cy + dx[b].item() * W],
+                          [-be, al, be * cx + (1 - al) * cy + dy[b].item() * H]])
+        ox = m[0, 0] * sx[b] + m[0, 1] * sy[b] + m[0, 2]
+        oy = m[1, 0] * sx[b] + m[1, 1] * sy[b] + m[1, 2]
+        xs = torch.arange(W, dtype=torch.float32).expand(H, W)
+        ys = torch.arange(H, dtype=torch.float32).reshape(H, 1).expand(H, W)
+        assert (ox - xs).abs().max() < 1e-3 and (oy - ys).abs().max() < 1e-3
+
+
+def test_combined_loader_reiterates_the_short_loader():
+    """mode max_size_cycle: the shorter loader starts a FRESH pass when it runs out (Lightning's CombinedLoader),
+    it is not replayed from a cache of its first pass."""
+    from denoising_diffusion_deep_fake_amd.trainer import CombinedLoader
+
+    class Counting:
+        def __init__(self, n):
+            self.n, self.passes = n, 0
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            self.passes += 1
+            return iter([(self.passes, i) for i in range(self.n)])
+    long, short = Counting(5), Counting(2)
+    got = list(CombinedLoader({"a": long, "b": short}))
+    assert len(got) == 5 and [g["a"][1] for g in got] == [0, 1, 2, 3, 4]
+    assert [g["b"] for g in got] == [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0)]
+    assert long.passes == 1 and short.passes == 3

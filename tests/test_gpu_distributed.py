@@ -183,3 +183,23 @@ def test_bench_contract_two_ranks(tmp_path):
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
     assert res["value"] > 0 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
     assert "roofline" in res and "cpu_baseline" not in res and "alt_f32x3" not in res   # N = 1 extras only
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver's scaling run calls it): the parent starts
+    torch.distributed.run as a child before touching the GPU and relays rank 0's single JSON line + the exit code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "4",
+           "--size", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and res["roofline"]["frac"] is not None and res["roofline"]["launches"] > 0

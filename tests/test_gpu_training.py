@@ -18,7 +18,7 @@ HP_FAKE = dict(mode="denoise", batch_size=2, learning_rate=0.01, adam_b1=0.5, ad
                cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
                noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
                std_b=[0.5] * 3, synthetic=True, image_size=64, synthetic_length=4, ema_beta=0.9999,
-               ema_update_every=1)
+               ema_update_every=1, augment=False)
 
 
 def _device_draws(seed, shape):
@@ -101,6 +101,48 @@ def test_train_deep_fake_steps(mode):
         assert "swap_difference/a" in lit._logged and "loss_swap/train_b" in lit._logged
     else:
         assert "loss_denoise/train_a" in lit._logged
+
+
+def test_swap_step_values_match_oracle():
+    """`training_swap_step_for_one_model` (d3f/train_deep_fake/lit_module.py:183-206) value for value: EMA teacher of
+    the other domain (train-mode BatchNorm, no_grad) renders the fake, explicit noise draws blend it, the student
+    denoises it; `loss_swap`, `swap_difference` and the student's gradient against oracle.swap_step in float64."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    torch.manual_seed(5)
+    lit = LitModule(**dict(HP_FAKE, mode="swap", augment=False)).cuda().train()
+    opts, _ = lit.configure_optimizers()
+    xa = oracle.synthetic_face_crops(2, 64, seed=41)
+    xb = oracle.synthetic_face_crops(2, 64, seed=42)
+    batch = {"a": {"image": xa.cuda(), "index": None}, "b": {"image": xb.cuda(), "index": None}}
+
+    def replica(model, dtype):
+        ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        return ref.to(dtype)
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    out = {}
+    for dtype in (torch.float32, torch.float64):
+        student = replica(lit.model_a, dtype)
+        teacher = oracle.EMA(replica(lit.model_b, dtype), beta=0.9999, update_every=1)
+        noise, y = _device_draws(99, xa.shape)
+        loss, diff, fake, pred = oracle.swap_step(xa.to(dtype), student, teacher, crit, noise.to(dtype),
+                                                  _oracle_r(y, 3).to(dtype))
+        loss.backward()
+        out[dtype] = (loss.item(), diff.item(), torch.cat([p.grad.reshape(-1) for p in student.parameters()]))
+    torch.manual_seed(99)
+    opts[0].zero_grad(set_to_none=True)
+    loss = lit.training_step(batch, 0, 0)      # optimizer 0: net a learns from the EMA copy of net b
+    loss.backward()
+    l32, d32, g32 = out[torch.float32]
+    l64, d64, g64 = out[torch.float64]
+    assert abs(loss.item() - l64) < max(4 * abs(l32 - l64), 5e-6), (loss.item(), l32, l64)
+    sd = float(lit._logged["swap_difference/a"])
+    assert abs(sd - d64) < max(4 * abs(d32 - d64), 1e-6 * d64), (sd, d32, d64)
+    assert float(lit._logged["loss_swap/train_a"]) == pytest.approx(loss.item())
+    e_hip, e_cpu = rel_l2(lit.model_a.flat_grads, g64), rel_l2(g32, g64)
+    assert e_hip < 3e-2 and e_hip < max(10 * e_cpu, 2e-5), (e_hip, e_cpu)
+    assert lit.ema_model_b._host_step == 1 and lit.model_b.flat_grads is None  # only the student was trained
 
 
 def test_ema_matches_oracle():
@@ -301,3 +343,155 @@ def test_cli_smoke(tmp_path):
     assert r.exit_code == 0, r.output + str(r.exception)
     rows = [l.split("\t") for l in out_list.read_text().strip().splitlines()]
     assert [r_[0] for r_ in rows] == names and {int(r_[1]) for r_ in rows} <= {0, 1, 2}
+
+
+def test_shift_scale_rotate_on_device():
+    """train_deep_fake's ShiftScaleRotate(p=0.7) on the GPU (d3f/train_deep_fake/lit_module.py:99-111): p=0 is the
+    identity, unselected samples pass through bit-exactly, selected ones equal grid_sample(bilinear, zeros) of the
+    same matrices, and about 70 % of the samples are selected."""
+    import torch.nn.functional as F
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule, ShiftScaleRotate
+    x = oracle.synthetic_face_crops(6, 64, seed=5)[:, :, :, :48].contiguous()
+    xc = x.cuda()
+    assert torch.equal(ShiftScaleRotate(p=0.0)(xc), xc)
+    aug = ShiftScaleRotate(shift_limit=0.2, scale_limit=0.1, rotate_limit=15, p=0.7)
+    draws = {"apply": torch.tensor([True, False, True, True, False, True]).cuda(),
+             "angle": torch.tensor([15.0, 3.0, -7.5, 0.0, 9.0, -15.0]).cuda(),
+             "scale": torch.tensor([1.1, 1.0, 0.9, 1.0, 1.05, 0.95]).cuda(),
+             "dx": torch.tensor([0.2, 0.1, -0.2, 0.0, 0.0, 0.05]).cuda(),
+             "dy": torch.tensor([-0.2, 0.0, 0.1, 0.0, 0.1, -0.05]).cuda()}
+    got = aug(xc, draws).cpu()
+    th = ShiftScaleRotate.theta(*(draws[k].cpu() for k in ("angle", "scale", "dx", "dy")), 64, 48)
+    want = F.grid_sample(x, F.affine_grid(th, list(x.shape), align_corners=False), mode="bilinear",
+                         padding_mode="zeros", align_corners=False)
+    for b in range(6):
+        if draws["apply"][b]:
+            assert (got[b] - want[b]).abs().max() < 2e-5, b
+            assert (got[b] == 0).any() or b == 3   # the zero border shows up (normalised units)
+        else:
+            assert torch.equal(got[b], x[b])
+    torch.manual_seed(0)
+    frac = torch.stack([aug.draw(64, "cuda")["apply"].float().mean() for _ in range(20)]).mean().item()
+    assert 0.64 < frac < 0.76
+    d = aug.draw(4096, "cuda")
+    assert d["angle"].abs().max() <= 15 and (d["scale"] - 1).abs().max() <= 0.1 + 1e-6 and d["dx"].abs().max() <= 0.2
+    # wired into the working training path, off with augment=False
+    assert LitModule(**dict(HP_FAKE, augment=True)).augmentation is not None
+    assert LitModule(**HP_FAKE).augmentation is None
+    lit = LitModule(**dict(HP_FAKE, augment=True)).cuda().train()
+    xa, xb = oracle.synthetic_face_crops(2, 64, seed=1).cuda(), oracle.synthetic_face_crops(2, 64, seed=2).cuda()
+    loss = lit.training_step({"a": {"image": xa, "index": None}, "b": {"image": xb, "index": None}}, 0, 1)
+    assert torch.isfinite(loss)
+
+
+def test_adam_state_is_torch_adam_state_both_ways():
+    """Checkpoint drop-in (d3f/train_deep_fake/start_training.py:19-23 resumes Lightning checkpoints whose
+    optimizer_states are torch.optim.Adam.state_dict()): FusedAdam writes that per-parameter form, reads it back,
+    and torch.optim.Adam itself can load what FusedAdam saved -- the moments and the step count survive."""
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    torch.manual_seed(11)
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    twin = copy.deepcopy(net).cuda().train()
+    twin.load_state_dict(net.state_dict())
+    fused = FusedAdam(net.parameters(), lr=0.01, betas=(0.5, 0.999), module=net)
+    plain = torch.optim.Adam(twin.parameters(), lr=0.01, betas=(0.5, 0.999))
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    g = torch.randn(2, 3, 64, 64, device="cuda")
+
+    def step(model, opt):
+        opt.zero_grad(set_to_none=True)
+        model(x).backward(g)
+        opt.step()
+    for _ in range(2):
+        step(net, fused)
+        step(twin, plain)
+    sd_f, sd_p = fused.state_dict(), plain.state_dict()
+    assert set(sd_f) == {"state", "param_groups"} and len(sd_f["state"]) == len(sd_p["state"]) == len(list(net.parameters()))
+    for i in (0, 5, len(sd_p["state"]) - 1):
+        assert float(sd_f["state"][i]["step"]) == float(sd_p["state"][i]["step"]) == 2.0
+        assert sd_f["state"][i]["exp_avg"].shape == sd_p["state"][i]["exp_avg"].shape
+        assert rel_l2(sd_f["state"][i]["exp_avg"], sd_p["state"][i]["exp_avg"]) < 1e-4
+        assert rel_l2(sd_f["state"][i]["exp_avg_sq"], sd_p["state"][i]["exp_avg_sq"]) < 1e-4
+    # cross-load: the reference's optimizer state into the fused one, the fused one into torch.optim.Adam
+    fused2 = FusedAdam(net.parameters(), lr=0.5, betas=(0.9, 0.9), module=net)
+    fused2.load_state_dict(sd_p)
+    assert fused2._step == 2 and fused2.param_groups[0]["lr"] == 0.01 and tuple(fused2.param_groups[0]["betas"]) == (0.5, 0.999)
+    plain2 = torch.optim.Adam(twin.parameters(), lr=0.5)
+    plain2.load_state_dict(sd_f)
+    net.load_state_dict(twin.state_dict())           # same weights again, then one more step on each side
+    step(net, fused2)
+    step(twin, plain2)
+    assert rel_l2(net.flat_params, torch.cat([p.detach().reshape(-1) for p in twin.parameters()])) < 1e-5
+    # an optimizer state that does not fit is refused, not zero-filled
+    bad = {"state": {0: sd_p["state"][0]}, "param_groups": sd_p["param_groups"]}
+    with pytest.raises(ValueError):
+        FusedAdam(net.parameters(), lr=0.01, module=net).load_state_dict(bad)
+
+
+def test_resume_from_a_reference_style_checkpoint(tmp_path):
+    """A hand-built Lightning 1.x checkpoint dict as the reference's Trainer writes it -- smp key names under
+    `model.`, torch.optim.Adam optimizer_states, CosineAnnealingLR state -- resumes with weights, Adam moments, step
+    count and lr intact; a checkpoint with a foreign key is refused (strict), not resumed from random init."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    from denoising_diffusion_deep_fake_amd.trainer import Trainer
+    torch.manual_seed(3)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    opt = torch.optim.Adam(ref.parameters(), lr=0.02)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4)
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+    x = oracle.synthetic_face_crops(2, 64, seed=9)
+    for _ in range(2):   # "epoch 0" of a reference run: two optimiser steps on the CPU
+        opt.zero_grad()
+        crit(ref(x), x).backward()
+        opt.step()
+    sched.step()
+    hp = dict(HP_DENOISER, max_epochs=2, cosine_scheduler_max_epoch=4)
+    ckpt = {"epoch": 0, "global_step": 2, "pytorch-lightning_version": "1.9.5",
+            "state_dict": {"model." + k: v for k, v in ref.state_dict().items()},
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()],
+            "hyper_parameters": hp}
+    path = tmp_path / "reference.ckpt"
+    torch.save(ckpt, path)
+    lit = LitModule.load_from_checkpoint(path)
+    tr = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False).fit(lit, ckpt_path=path)
+    # max_epochs=1 and the checkpoint closed epoch 0: nothing is trained, only restored
+    assert tr.current_epoch == 1 and tr.global_step == 2
+    o = tr.optimizers[0]
+    assert o._step == 2 and o.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"])
+    want_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref.parameters()])
+    want_v = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref.parameters()])
+    assert torch.equal(o.exp_avg.cpu(), want_m) and torch.equal(o.exp_avg_sq.cpu(), want_v)
+    assert torch.equal(lit.model.flat_params.cpu(), torch.cat([p.detach().reshape(-1) for p in ref.parameters()]))
+    # ... and training continues from there: epoch 1 = two more steps
+    tr2 = Trainer(max_epochs=2, default_root_dir=tmp_path, enable_checkpointing=False).fit(
+        LitModule.load_from_checkpoint(path), ckpt_path=path)
+    assert tr2.global_step == 4 and tr2.optimizers[0]._step == 4
+    bad_sd = dict(ckpt["state_dict"])
+    bad_sd["model.encoder.conv1.weight_x"] = bad_sd.pop("model.encoder.conv1.weight")
+    bad = dict(ckpt, state_dict=bad_sd)
+    torch.save(bad, tmp_path / "bad.ckpt")
+    with pytest.raises(RuntimeError):
+        Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False).fit(LitModule(**hp), ckpt_path=tmp_path / "bad.ckpt")
+
+
+def test_ragged_last_batch_and_mid_epoch_resume(tmp_path):
+    """the reference's loaders keep the ragged last batch (no drop_last, d3f/train_denoiser/lit_module.py:82-87):
+    10 images at bs 4 are 3 steps per epoch, the last one on 2 images; a checkpoint written mid-epoch resumes inside
+    that epoch instead of skipping the rest of it."""
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    from denoising_diffusion_deep_fake_amd.trainer import Trainer
+    hp = dict(HP_DENOISER, synthetic_length=10, max_epochs=1, default_root_dir=str(tmp_path))
+    torch.manual_seed(2)
+    lit = LitModule(**hp)
+    assert len(lit.train_dataloader()) == 3
+    tr = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False, max_steps=2).fit(lit)
+    assert tr.global_step == 2
+    tr._batches_done = 2            # what ModelCheckpoint(train_time_interval=...) would have seen after batch 2
+    tr.current_epoch = 0
+    tr.save_checkpoint(tmp_path / "mid.ckpt")
+    tr2 = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False).fit(
+        LitModule.load_from_checkpoint(tmp_path / "mid.ckpt"), ckpt_path=tmp_path / "mid.ckpt")
+    assert tr2.global_step == 3 and tr2.current_epoch == 1   # one remaining (ragged) batch of epoch 0 was trained

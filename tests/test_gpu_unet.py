@@ -325,3 +325,49 @@ def test_baseline_config_128_bs16():
           % (e_fwd, e_fwd_cpu, e_g, e_g_cpu))
     assert _within(e_fwd, e_fwd_cpu, CAP_FWD, 2e-6)
     assert _within(e_g, e_g_cpu, CAP_GRAD_FLAT, 2e-5, NOISE_GRAD)
+
+
+def test_two_forwards_before_backward_and_no_grad_in_between():
+    """smp.Unet allows `crit(net(x1)) + crit(net(x2))` and a no_grad forward between a forward and its backward.
+    Every recorded forward leases its workspace until its backward has run, so both graphs keep their own
+    activations: the summed gradient must equal the two single-pass gradients added."""
+    import oracle
+    from denoising_diffusion_deep_fake_amd._lib import D3FError
+    _, net = _pair(seed=4)
+    net.train()
+    x1 = oracle.synthetic_face_crops(2, 64, seed=21).cuda()
+    x2 = oracle.synthetic_face_crops(2, 64, seed=22).cuda()
+    g1 = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    g2 = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def single(x, g):
+        for p in net.parameters():
+            p.grad = None
+        y = net(x)
+        y.backward(g)
+        return y.detach().clone(), net.flat_grads.clone()
+
+    y1, ga = single(x1, g1)
+    y2, gb = single(x2, g2)
+    for p in net.parameters():
+        p.grad = None
+    ya = net(x1)
+    yb = net(x2)                      # same shape: must NOT overwrite ya's activations
+    with torch.no_grad():
+        net(x2)                       # logging-style forward in between
+    assert torch.equal(ya, y1) and torch.equal(yb, y2)
+    ((ya * g1).sum() + (yb * g2).sum()).backward()
+    total = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert rel_l2(total, ga + gb) < 1e-6
+    pool = next(iter(net._rt["engines"].values()))
+    assert len(pool) == 2 and not any(e.in_use for e in pool)
+    # a graph that is dropped without backward gives its workspace back
+    y = net(x1)
+    assert sum(e.in_use for e in pool) == 1
+    del y
+    assert not any(e.in_use for e in pool)
+    # retain_graph-style second backward is refused loudly, not answered from stale activations
+    y = net(x1)
+    y.backward(g1, retain_graph=True)
+    with pytest.raises((D3FError, RuntimeError)):
+        y.backward(g1)
