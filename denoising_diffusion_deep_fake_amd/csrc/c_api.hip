@@ -104,13 +104,22 @@ static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool a
   D3F_CHECK(s2 ? (g.Ho * 2 == d->H && g.Wo * 2 == d->W) : (g.Ho == d->H && g.Wo == d->W),
             "conv_backward_data: needs a 'same' (stride 1) or exactly halving (stride 2) conv");
   std::memset(&p, 0, sizeof(p));
-  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = g.CoutD; p.C1 = 0;
-  p.H0s = g.Ho; p.W0s = g.Wo; p.shift0 = s2; p.zi = s2;
-  p.Ho = d->H; p.Wo = d->W; p.Cout = g.Cin; p.CoutPad = g.CinRows; p.Kpad = g.KpadD;
-  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
-  p.M = d->B * d->H * d->W;
   p.mode = CONV_DGRAD;
   p.out_c0 = d->C1 > 0 ? d->C0 : g.Cin;
+  p.Cout = g.Cin; p.CoutPad = g.CinRows; p.Kpad = g.KpadD; p.C0 = g.CoutD; p.C1 = 0; p.B = d->B;
+  if (parity_dgrad_applies(dtype, d->stride, d->KH, d->pad, g.CoutD, d->C1)) {
+    // stride 2: four plain sub-convolutions over dY, one per output-parity class (conv_igemm.hip)
+    p.par = d->KH == 3 ? 1 : 2;
+    p.Hv = p.Ho = p.H0s = g.Ho; p.Wv = p.Wo = p.W0s = g.Wo;
+    p.KH = p.KW = d->KH == 3 ? 2 : 1; p.stride = 1; p.pad = 0;
+    p.M = d->B * g.Ho * g.Wo;
+    return conv_igemm_plan(p, dtype, false);
+  }
+  p.Hv = d->H; p.Wv = d->W;
+  p.H0s = g.Ho; p.W0s = g.Wo; p.shift0 = s2; p.zi = s2;
+  p.Ho = d->H; p.Wo = d->W;
+  p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
+  p.M = d->B * d->H * d->W;
   return conv_igemm_plan(p, dtype, allow_splitk);
 }
 
@@ -237,6 +246,10 @@ int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float
   D3F_CHECK(h && name && workspace && out_nchw, "unet_export: null argument");
   return h->e.export_tensor(name, workspace, out_nchw, (hipStream_t)stream);
 }
+int d3f_unet_export_shape(d3f_unet_t h, const char* name, int32_t dims[3]) {
+  D3F_CHECK(h && name && dims, "unet_export_shape: null argument");
+  return h->e.export_shape(name, dims);
+}
 
 // ---- single operators -----------------------------------------------------------------------
 size_t d3f_conv_packed_bytes(int dtype, const d3f_conv_desc* d, int which) {
@@ -250,7 +263,9 @@ int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, voi
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
   return pack_weights_launch(dtype, w, d->Cout, d->CinReal, g.Cin, d->KH, d->KW, w_fwd, g.CoutPad, g.Kpad,
-                             w_dgrad, g.CinRows, g.KpadD, (hipStream_t)stream);
+                             w_dgrad, g.CinRows, g.KpadD,
+                             parity_dgrad_applies(dtype, d->stride, d->KH, d->pad, g.CoutD, d->C1) ? 2 : 1,
+                             (hipStream_t)stream);
 }
 size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
   ConvParams p;
@@ -281,6 +296,10 @@ int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, co
   D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
   p.src0 = dy; p.w = w_dgrad; p.out0 = dx0; p.out1 = dx1; p.acc0 = acc0; p.acc1 = acc1;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  if (p.par == 2 && !acc0) {  // 1x1 stride 2: only even pixels receive a gradient; the others are zero
+    const size_t es = sdt(dtype) == D3F_F32 ? 4 : 2;
+    D3F_HIP(hipMemsetAsync(dx0, 0, (size_t)4 * p.M * p.Cout * es, (hipStream_t)stream));
+  }
   return conv_igemm_launch(p, dtype, (hipStream_t)stream);
 }
 static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {
@@ -312,8 +331,11 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
   w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
   if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
+  WgradDst dst;
+  dst.n = 1;
+  dst.dw[0] = dw;
   return wgrad_reduce_launch(w.partial, w.splits, w.Cout, d->Cout, d->C0 + d->C1, d->CinReal, d->KH, d->KW,
-                             dw, 0, (hipStream_t)stream);
+                             dst, (hipStream_t)stream);
 }
 
 int d3f_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma,

@@ -115,6 +115,8 @@ struct ConvParams {
   int zi;              // 1 (with shift0): only even (iy, ix) exist (zero insertion = dgrad of stride 2)
   int Ho, Wo, Cout;    // output extent, real output channels
   int CoutPad, Kpad;
+  int w_ld;            // elements between packed weight rows (= Kpad; filled by plan)
+  int par;             // CONV_DGRAD of a stride-2 conv by output-parity classes: 1 = 3x3 pad 1, 2 = 1x1 pad 0 (0: off)
   int KH, KW, stride, pad;
   int M;               // B*Ho*Wo
   int tiles_m, tiles_n;
@@ -139,6 +141,12 @@ struct ConvParams {
 struct ConvTile {
   int BM, BN;
 };
+// Does the data gradient of this convolution run as the parity-class decomposition (ConvParams::par)?  The weight
+// packers (pointwise.hip) store the flipped taps class by class exactly when it does, so both ask this one function.
+static inline bool parity_dgrad_applies(int dtype, int stride, int k, int pad, int CoutD, int C1) {
+  const int bke = dtype == D3F_BF16 ? 64 : 32;
+  return stride == 2 && C1 == 0 && (CoutD % bke) == 0 && ((k == 3 && pad == 1) || (k == 1 && pad == 0));
+}
 // chooses the tile configuration for a problem; tiles_m/tiles_n are filled in p.
 // allow_splitk: the caller can provide `partial` (conv_splitk_floats(p) floats) -- deep layers
 // whose M x Cout yields too few workgroups then split the K loop over grid.y.
@@ -165,12 +173,28 @@ struct WgradParams {
   int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
   double flops;  // algorithmic FLOPs of this launch, for profiling
 };
-int wgrad_plan(WgradParams& p, int dtype);  // fills splits/tiles; returns 0
-size_t wgrad_partial_floats(const WgradParams& p);
-int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
-// sums the slabs [splits][CoutP][KH*KW][Cin] and writes the PyTorch-layout gradient
-// [Cout][CinReal][KH][KW] (fp32), dropping padded channels
+// Grouped launches: layers of identical shape (the 3x3 stride-1 convolutions inside one ResNet stage) run their
+// weight gradients as ONE launch, blockIdx.z = member.  With G members there are G times as many (tap, co, ci)
+// tiles to spread over the chip, so the pixel range is cut into G times fewer slabs: less partial-slab traffic,
+// fewer and longer launches.  Member z reads dy[z] / src0[z] and writes its slabs at partial + z * splits * |W|.
+constexpr int WG_MAXG = 12;
+struct WgradGroup {
+  const void* dy[WG_MAXG];
+  const void* src0[WG_MAXG];
+  int n;
+};
+struct WgradDst {
+  float* dw[WG_MAXG];
+  int n;
+};
+// fills splits/tiles for a launch of `group` identical layers; returns 0
+int wgrad_plan(WgradParams& p, int dtype, int group = 1);
+size_t wgrad_partial_floats(const WgradParams& p);  // per group member
+int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);  // one layer: p.dy / p.src0 / p.src1
+int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hipStream_t stream);
+// sums the slabs [member][splits][CoutP][KH*KW][Cin] in a fixed order and writes each member's PyTorch-layout
+// gradient [Cout][CinReal][KH][KW] (fp32), dropping padded channels; one launch for the whole group
 int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
-                        int KH, int KW, float* dw, int accumulate, hipStream_t stream);
+                        int KH, int KW, const WgradDst& dst, hipStream_t stream);
 
 }  // namespace d3f

@@ -239,6 +239,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const int Cin = p.C0 + p.C1;
 
+  // Parity-decomposed data gradient of a stride-2 convolution (p.par != 0; host: plan_parity_dgrad).  dX at input
+  // pixel (2jy+py, 2jx+px) only receives the filter taps of matching parity, so each of the four classes is a plain
+  // stride-1 convolution over dY with a (1 or 2) x (1 or 2) kernel -- 9 taps per 4 output pixels instead of the 36
+  // that reading dY through zero insertion multiplies.  blockIdx.z = class, longest first: (1,1) (1,0) (0,1) (0,0);
+  // the packed weight rows hold the taps class by class (pointwise.hip: dgrad_tap_slot), so a class is a k-offset.
+  int KH_ = p.KH, KW_ = p.KW, Kc = p.Kpad, par_py = 0, par_px = 0;
+  unsigned wk0 = 0;  // first weight element (k index) of this launch slice
+  if (p.par == 1) {       // 3x3, pad 1
+    const int z = blockIdx.z;
+    par_py = z < 2 ? 1 : 0;
+    par_px = (z == 0 || z == 2) ? 1 : 0;
+    KH_ = 1 + par_py;
+    KW_ = 1 + par_px;
+    Kc = KH_ * KW_ * p.C0;
+    wk0 = (unsigned)((z == 0 ? 0 : z == 1 ? 4 : z == 2 ? 6 : 8) * p.C0);
+  } else if (p.par == 2) {  // 1x1, pad 0: only even pixels receive anything (the launch covers class (0,0) alone)
+    KH_ = KW_ = 1;
+    Kc = p.C0;
+  }
+
   // ---- per-row output pixel -> input origin -----------------------------------------
   int iy0[NVA], ix0[NVA], bidx[NVA];
   {
@@ -270,11 +290,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const bool rowok = iy0[i] > -(1 << 23);
       rowoff[i] = (unsigned)(((bidx[i] * p.Hv + iy0[i]) * p.Wv + ix0[i]) * p.C0 + chunk * VE) * (unsigned)sizeof(T);
       unsigned mk = 0;
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw) {
+      for (int kh = 0; kh < KH_; ++kh)
+        for (int kw = 0; kw < KW_; ++kw) {
           const int iy = iy0[i] + kh, ix = ix0[i] + kw;
           const unsigned ok = (unsigned)(rowok & ((unsigned)iy < (unsigned)p.Hv) & ((unsigned)ix < (unsigned)p.Wv));
-          mk |= ok << (kh * p.KW + kw);
+          mk |= ok << (kh * KW_ + kw);
         }
       vmask[i] = mk;
     }
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < M_::NREG; ++r) acc[i][j][r] = 0.f;
 
-  const int nk_total = p.Kpad / BKE;
+  const int nk_total = Kc / BKE;
   // split-K: grid.y cuts the k-tile range; each slice writes raw accumulators to its slab
   const int kt_begin = (int)((long)nk_total * blockIdx.y / p.splitk);
   const int kt_end = (int)((long)nk_total * (blockIdx.y + 1) / p.splitk);
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int cpos = kt_begin * BKE;
     const int tap = cpos / Cin;
     t_c = cpos - tap * Cin;
-    t_kh = tap / p.KW;
-    t_kw = tap - t_kh * p.KW;
+    t_kh = tap / KW_;
+    t_kw = tap - t_kh * KW_;
   }
 
   // Buffer descriptors (wave-uniform): lanes whose tap falls outside the image, whose row is past M
@@ -308,7 +328,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t r0 = make_rsrc(p.src0, p.src0_bytes);
   const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
-  const int w_row_bytes = X3 ? p.Kpad * 2 : p.Kpad * (int)sizeof(T);
+  const int w_row_bytes = X3 ? p.w_ld * 2 : p.w_ld * (int)sizeof(T);
+  const unsigned wk0_bytes = wk0 * (X3 ? 2u : (unsigned)sizeof(T));
   unsigned woff[NVB];
   int x3_bdst[NVB];  // x3: LDS dword offset of this thread's weight pieces inside the B planes (-1: no piece)
 #pragma unroll
@@ -317,12 +338,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int slot = j * 256 + tid, plane = slot / (BN * 4), within = slot % (BN * 4);
       const int row = within >> 2, c = within & 3, n = n0 + row;
       const bool ok = slot < 3 * BN * 4;
-      woff[j] = (ok && n < p.CoutPad) ? (unsigned)(plane * (p.CoutPad * w_row_bytes) + n * w_row_bytes + c * 16) : BUF_OOB;
+      woff[j] = (ok && n < p.CoutPad) ? (unsigned)(plane * (p.CoutPad * w_row_bytes) + n * w_row_bytes + c * 16) + wk0_bytes : BUF_OOB;
       x3_bdst[j] = ok ? plane * BPL + row * X3_ROW + ((c ^ ((row >> 2) & 3)) << 2) : -1;
     } else {
       const int row = rbase + 32 * j;
       const int n = n0 + row;
-      woff[j] = (row < BN && n < p.CoutPad) ? (unsigned)(n * w_row_bytes + chunk * 16) : BUF_OOB;
+      woff[j] = (row < BN && n < p.CoutPad) ? (unsigned)(n * w_row_bytes + chunk * 16) + wk0_bytes : BUF_OOB;
       x3_bdst[j] = 0;
     }
   }
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // between MFMAs.
   const bool sc_pow2 = (Cin & (Cin - 1)) == 0;
   const int sc_shift = __builtin_ctz((unsigned)Cin | 0x80000000u);
-  const unsigned sc_kw_magic = (65536u + (unsigned)p.KW - 1u) / (unsigned)p.KW;
+  const unsigned sc_kw_magic = (65536u + (unsigned)KW_ - 1u) / (unsigned)KW_;
   struct TileCtx {
     int kh, kw, c, kt;
     int tapvalid, parity_mask, Cs, sh, Hs, Ws;
@@ -352,21 +373,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int tap = sc_pow2 ? (kk >> sc_shift) : kk / Cin;
       x.c = kk - tap * Cin;
       x.kh = (int)(((unsigned)tap * sc_kw_magic) >> 16);
-      x.kw = tap - x.kh * p.KW;
-      x.tapvalid = tap < p.KH * p.KW ? 1 : 0;
+      x.kw = tap - x.kh * KW_;
+      x.tapvalid = tap < KH_ * KW_ ? 1 : 0;
     } else {
       x.kh = t_kh;
       x.kw = t_kw;
       x.from0 = t_c < p.C0;
       x.c = (x.from0 ? t_c : t_c - p.C0) + chunk * VE;
       x.tapdelta = (unsigned)((t_kh * p.Wv + t_kw) * p.C0 + t_c) * (unsigned)sizeof(T);
-      x.tapbit = (unsigned)(t_kh * p.KW + t_kw);
+      x.tapbit = (unsigned)(t_kh * KW_ + t_kw);
       // branch-free advance (keeps the steady-state loop body one basic block)
       t_c += BKE;
       const int wrap_c = t_c >= Cin ? 1 : 0;
       t_c = wrap_c ? 0 : t_c;
       t_kw += wrap_c;
-      const int wrap_w = t_kw == p.KW ? 1 : 0;
+      const int wrap_w = t_kw == KW_ ? 1 : 0;
       t_kw = wrap_w ? 0 : t_kw;
       t_kh += wrap_w;
     }
@@ -531,16 +552,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // row -- and two register sets keep the loads of tiles t+2 and t+3 in flight while tile t computes.
     const unsigned step_bytes = BKE * (unsigned)sizeof(T);  // activations; weights advance by WSTEP
     const int cpt = Cin / BKE;                                        // k-tiles per tap
-    const unsigned rowjump = (unsigned)((p.Wv - p.KW) * p.C0) * (unsigned)sizeof(T);
+    const unsigned rowjump = (unsigned)((p.Wv - KW_) * p.C0) * (unsigned)sizeof(T);
     unsigned ld_delta, ld_bit, ld_w;                                  // state of the LOAD stream (runs ahead)
     int ld_cleft, ld_kwleft;
     {
       const int tap0 = kt_begin / cpt, c0 = kt_begin - tap0 * cpt;
-      const int kh0 = tap0 / p.KW, kw0 = tap0 - kh0 * p.KW;
+      const int kh0 = tap0 / KW_, kw0 = tap0 - kh0 * KW_;
       ld_delta = (unsigned)((kh0 * p.Wv + kw0) * p.C0 + c0 * BKE) * (unsigned)sizeof(T);
       ld_bit = (unsigned)tap0;
       ld_cleft = cpt - c0;
-      ld_kwleft = p.KW - kw0;
+      ld_kwleft = KW_ - kw0;
       ld_w = (unsigned)kt_begin * WSTEP;
     }
     uint4 ra2[NVA], rb2[NVB];  // second register set
@@ -560,7 +581,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ld_bit += (unsigned)tapwrap;
       ld_kwleft -= tapwrap;
       const int rowwrap = (ld_kwleft == 0) ? 1 : 0;
-      ld_kwleft = rowwrap ? p.KW : ld_kwleft;
+      ld_kwleft = rowwrap ? KW_ : ld_kwleft;
       ld_delta += rowwrap ? rowjump : 0u;
     };
     auto issue_all = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
@@ -838,7 +859,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int row = rv0 + i * RSTEP, m = m0 + row;
         if (m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
-        T* dst = base + (long)m * ld;
+        long orow = m;
+        if (p.par) {  // row m = (b, jy, jx) of this parity class -> input pixel (2jy+py, 2jx+px)
+          const int HoWo = p.Ho * p.Wo;
+          const int b = m / HoWo, r = m - b * HoWo;
+          const int jy = r / p.Wo, jx = r - jy * p.Wo;
+          orow = ((long)b * (2 * p.Ho) + 2 * jy + par_py) * (2 * p.Wo) + 2 * jx + par_px;
+        }
+        T* dst = base + orow * ld;
         if (accum) {
           const float4 o = load4(dst);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -897,6 +925,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 constexpr int SK_ROWS = 8;   // rows per reduce workgroup (small: the reduce is latency-bound, it wants many workgroups)
 constexpr int SK_MAX = 8;    // upper bound of splitk (plan)
 
+// 16-byte stores of 4 consecutive channels (4 f32, or 4 bf16 as 8 bytes)
+template <typename T> __device__ __forceinline__ void sk_store4(T* dst, const float (&v)[4]);
+template <> __device__ __forceinline__ void sk_store4<float>(float* dst, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void sk_store4<bf16_t>(bf16_t* dst, const float (&v)[4]) {
+  uint2 w;
+  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(dst) = w;
+}
+template <typename T> __device__ __forceinline__ void sk_load4(const T* src, float (&v)[4]);
+template <> __device__ __forceinline__ void sk_load4<float>(const float* src, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(src);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void sk_load4<bf16_t>(const bf16_t* src, float (&v)[4]) {
+  const uint2 w = *reinterpret_cast<const uint2*>(src);
+  v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+  v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   __shared__ float red[256 * 4 * 2];
@@ -906,11 +956,26 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int m_begin = blockIdx.x * SK_ROWS;
   const int m_end = min(m_begin + SK_ROWS, p.M);
   const long MN = (long)p.M * p.Cout;
+  const int n = cv * 4;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
   T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
+  // per-channel coefficients of this thread's four channels: loaded once (a thread keeps its vector column)
+  float c_sc[4] = {}, c_sf[4] = {}, c_mu[4] = {}, c_is[4] = {};
+  const bool fused_bn = p.mode == CONV_DGRAD && p.bn_partial != nullptr;
+  if (p.mode == CONV_EVAL_FUSED) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c_sc[k] = p.scale[n + k]; c_sf[k] = p.shift[n + k]; }
+  } else if (fused_bn) {
+    const int C = p.Cout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c_mu[k] = p.bn_coef[n + k]; c_is[k] = p.bn_coef[C + n + k];
+      c_sc[k] = p.bn_coef[2 * C + n + k]; c_sf[k] = p.bn_coef[3 * C + n + k];
+    }
+  }
   for (int m = m_begin + r0; m < m_end; m += RP) {
-    const long e = (long)m * p.Cout + cv * 4;
+    const long e = (long)m * p.Cout + n;
     // all slabs in flight at once (splitk is wave-uniform: scalar branches), summed in slab order
     float4 w[SK_MAX];
 #pragma unroll
@@ -926,43 +991,42 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
       for (int k = 0; k < 4; ++k) {
         s1[k] += vv[k];
         s2[k] += vv[k] * vv[k];
-        o0[e + k] = from_f32<T>(vv[k]);
       }
+      sk_store4<T>(o0 + e, vv);
     } else if (p.mode == CONV_EVAL_FUSED) {  // folded BatchNorm (+ residual) (+ ReLU), as the fused epilogue
-      const int n = cv * 4;
-      const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.res != nullptr) sk_load4<T>(reinterpret_cast<const T*>(p.res) + e, r);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float x = vv[k] * p.scale[n + k] + p.shift[n + k];
-        if (res != nullptr) x += to_f32<T>(res[e + k]);
+        float x = vv[k] * c_sc[k] + c_sf[k];
+        if (p.res != nullptr) x += r[k];
         if (p.relu) x = fmaxf(x, 0.f);
-        o0[e + k] = from_f32<T>(x);
+        vv[k] = x;
       }
+      sk_store4<T>(o0 + e, vv);
     } else {  // CONV_DGRAD
-      const int n = cv * 4;
       const bool first = n < p.out_c0;
       T* __restrict__ dst = first ? o0 + (long)m * p.out_c0 + n : o1 + (long)m * (p.Cout - p.out_c0) + (n - p.out_c0);
       const bool accum = first ? p.acc0 : p.acc1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float x = vv[k];
-        if (accum) x += to_f32<T>(dst[k]);
-        dst[k] = from_f32<T>(x);
-      }
-      if (p.bn_partial != nullptr) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel)
-        const int C = p.Cout;
-        const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+      if (fused_bn) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel): on the RAW sum
+        float yy[4];
+        sk_load4<T>(reinterpret_cast<const T*>(p.bn_y) + e, yy);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float yy = to_f32<T>(yb[e + k]);
-          const float g = (yy * p.bn_coef[2 * C + n + k] + p.bn_coef[3 * C + n + k]) > 0.f ? vv[k] : 0.f;
+          const float g = (yy[k] * c_sc[k] + c_sf[k]) > 0.f ? vv[k] : 0.f;
           s1[k] += g;
-          s2[k] += g * ((yy - p.bn_coef[n + k]) * p.bn_coef[C + n + k]);
+          s2[k] += g * ((yy[k] - c_mu[k]) * c_is[k]);
         }
       }
+      if (accum) {
+        float o[4];
+        sk_load4<T>(dst, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] += o[k];
+      }
+      sk_store4<T>(dst, vv);
     }
   }
-  const bool fused_bn = p.mode == CONV_DGRAD && p.bn_partial != nullptr;
   if ((p.mode == CONV_RAW_STATS && p.stats != nullptr) || fused_bn) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1026,13 +1090,23 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16 || dtype == D3F_F32X3, "conv: bad dtype %d", dtype);
   D3F_CHECK((p.C0 % ve) == 0 && (p.C1 % ve) == 0, "conv: channels (%d,%d) not a multiple of %d",
             p.C0, p.C1, ve);
-  D3F_CHECK(p.Kpad % bke == 0 && p.Kpad >= p.KH * p.KW * (p.C0 + p.C1),
+  D3F_CHECK(p.Kpad % bke == 0 && (p.par || p.Kpad >= p.KH * p.KW * (p.C0 + p.C1)),
             "conv: Kpad %d inconsistent with K=%d", p.Kpad, p.KH * p.KW * (p.C0 + p.C1));
-  if (is_small_c(p, dtype)) {
+  if (p.par) {
+    // parity-decomposed stride-2 data gradient: four plain sub-convolutions over dY (kernel comment)
+    D3F_CHECK(p.mode == CONV_DGRAD && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.stride == 1 && p.pad == 0 &&
+                  p.Hv == p.Ho && p.Wv == p.Wo && !is_small_c(p, dtype) && p.out_c0 == p.Cout &&
+                  p.bn_partial == nullptr,
+              "conv: parity data gradient needs a single-source, single-destination stride-1 description");
+    D3F_CHECK((p.par == 1 && p.KH == 2 && p.KW == 2 && p.Kpad == 9 * p.C0) ||
+                  (p.par == 2 && p.KH == 1 && p.KW == 1 && p.Kpad == p.C0),
+              "conv: parity data gradient: kernel %dx%d, Kpad %d, C0 %d", p.KH, p.KW, p.Kpad, p.C0);
+  } else if (is_small_c(p, dtype)) {
     D3F_CHECK(p.C1 == 0, "conv: small-channel mode takes one source");
   } else {
     D3F_CHECK(p.Kpad == p.KH * p.KW * (p.C0 + p.C1), "conv: regular mode needs Kpad == K");
   }
+  p.w_ld = p.Kpad;
   D3F_CHECK(p.shift0 == 0 || p.shift0 == 1, "conv: shift0");
   D3F_CHECK(!p.zi || p.shift0 == 1, "conv: zero insertion needs shift0");
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "conv: src0 extent");
@@ -1058,7 +1132,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob
   int f0, f1, f2;
   const bool forced = forced_tile(&f0, &f1, &f2);
-  if (allow_splitk && !no_splitk && !is_small_c(p, dtype) && (base < 384 || forced) && (p.Cout % 4) == 0 && vc <= 256 &&
+  if (allow_splitk && !p.par && !no_splitk && !is_small_c(p, dtype) && (base < 384 || forced) && (p.Cout % 4) == 0 && vc <= 256 &&
       (256 % vc) == 0 && (p.mode == CONV_RAW_STATS || p.mode == CONV_DGRAD) &&
       (p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0)) {
     int sk = (int)((640 + base - 1) / base);
@@ -1076,7 +1150,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool X3>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk), block(256);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, p.par == 1 ? 4u : 1u), block(256);
   static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
   const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
   if (smallc)
@@ -1105,13 +1179,15 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const bool smallc = is_small_c(p, dtype);
   ConvParams q = p;
   if (q.partial == nullptr) q.splitk = 1;
-  // timing-only ablation (results are wrong): zero-record descriptors make every buffer load return
-  // zeros at once while the instruction stream, waits and barriers stay identical
+#ifdef D3F_PROFILING
+  // timing-only ablation (results are wrong; profiling builds only, never in the shipped library): zero-record
+  // descriptors make every buffer load return zeros at once while the instruction stream, waits and barriers stay
   static const char* ablate = getenv("D3F_ABLATE_LOADS");
   if (ablate != nullptr) {
     if (ablate[0] == 'a' || ablate[0] == 'b') q.src0_bytes = q.src1_bytes = 0;  // activations
     if (ablate[0] == 'w' || ablate[0] == 'b') q.w_bytes = 0;                    // weights
   }
+#endif
   D3F_CHECK(q.splitk == 1 || q.stat_rows == cdiv(q.M, SK_ROWS), "conv: split-K params were not planned");
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);

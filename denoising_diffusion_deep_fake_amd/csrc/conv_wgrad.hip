@@ -64,7 +64,7 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // channel per lane) are gathered with ds_read_b64_tr_b16, the hardware transposing read of gfx950: two reads
 // per fragment, conflict-free because the 4 rows x 64 B a half-wave touches are contiguous.
 template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, const WgradGroup grp) {
   constexpr int VE = Elem<T>::VE;
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
@@ -98,10 +98,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int split = blockIdx.y;
   const int Cin = p.C0 + p.C1;
 
-  // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip)
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
-  const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(p.src0, p.src0_bytes);
-  const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
+  // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip); blockIdx.z = group member
+  const int member = blockIdx.z;
+  const void* const dy_ptr = grp.dy[member];
+  const void* const src0_ptr = grp.src0[member];
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy_ptr, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(src0_ptr, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : src0_ptr, p.src1_bytes);
 
   // loader roles: vector id = tid + i*256 -> (row, vector column)
   const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*YRS
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
   // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int taps = p.KH * p.KW;
-  float* __restrict__ slab = p.partial + (long)split * p.Cout * taps * Cin;
+  float* __restrict__ slab = p.partial + ((long)member * p.splits + split) * p.Cout * taps * Cin;
   if (KSPLIT > 1) {
     // the 4 waves hold partial sums of the same 32x32 tile: reduce through LDS
     float* red = lds;
@@ -342,33 +345,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-// Each thread owns one weight element and sums its `splits` slab values with 8 loads in flight
-// (a serial loop is latency-bound: 114 dependent-issue round trips for the layer1 shapes).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                           int splits, int CoutP, int Cout, int Cin,
-                                                           int CinReal, int taps,
-                                                           float* __restrict__ dw, int accumulate) {
-  const long n = (long)CoutP * taps * Cin;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-    const int ci = (int)(e % Cin);
-    const long t = e / Cin;
-    const int tap = (int)(t % taps);
-    const int co = (int)(t / taps);
-    if (ci >= CinReal || co >= Cout) continue;
-    const float* __restrict__ src = partial + e;
-    float acc[8];
+// Slab reduce + layout change.  One workgroup per (output filter, group member, channel chunk of CB inputs): the
+// chunk's [tap][CB] segments of every slab are summed with 16-byte loads and written out as the PyTorch [ci][tap]
+// run -- both global sides coalesced.  The 256 threads are nsg slab groups x VB vector columns: group g sums slabs
+// g, g + nsg, ... (8 loads in flight each) and the groups are combined through LDS in group order -- a fixed
+// summation tree, bitwise reproducible.  (Round 1's one-element-per-thread form read 4 bytes per lane, scattered
+// 4-byte stores `taps` floats apart and ran at 0.8 TB/s; a 64-filter layer with 114 slabs needs both the channel
+// chunks -- enough workgroups -- and the slab groups -- enough loads in flight.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int CoutP,
+                                                           int Cin, int CinReal, int taps, int CB, int nsg, int VB,
+                                                           const WgradDst dst) {
+  extern __shared__ __attribute__((aligned(16))) float row[];  // [nsg][taps][CB + 1]
+  const int co = blockIdx.x, member = blockIdx.y, c0 = blockIdx.z * CB;
+  const int rowlen = taps * Cin;
+  const long n = (long)CoutP * rowlen;
+  const float* __restrict__ src = partial + (long)member * splits * n + (long)co * rowlen + c0;
+  const int LR = CB + 1, plane = taps * LR, nvec = taps * CB / 4;
+  const int sg = threadIdx.x / VB, vb = threadIdx.x - sg * VB;
+  if (sg < nsg) {
+    for (int v = vb; v < nvec; v += VB) {
+      const int e = v * 4, tap = e / CB, cl = e - tap * CB;  // CB % 4 == 0: the four elements share a tap
+      const float* __restrict__ s0 = src + tap * Cin + cl;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = sg;
+      for (; k + 7 * nsg < splits; k += 8 * nsg) {  // eight loads in flight
+        float4 w[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    int k = 0;
-    for (; k + 8 <= splits; k += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += src[(long)(k + u) * n];
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(s0 + (long)(k + u * nsg) * n);
+        float4 t;
+        t.x = ((w[0].x + w[1].x) + (w[2].x + w[3].x)) + ((w[4].x + w[5].x) + (w[6].x + w[7].x));
+        t.y = ((w[0].y + w[1].y) + (w[2].y + w[3].y)) + ((w[4].y + w[5].y) + (w[6].y + w[7].y));
+        t.z = ((w[0].z + w[1].z) + (w[2].z + w[3].z)) + ((w[4].z + w[5].z) + (w[6].z + w[7].z));
+        t.w = ((w[0].w + w[1].w) + (w[2].w + w[3].w)) + ((w[4].w + w[5].w) + (w[6].w + w[7].w));
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      for (; k + nsg < splits; k += 2 * nsg) {
+        const float4 a = *reinterpret_cast<const float4*>(s0 + (long)k * n);
+        const float4 b = *reinterpret_cast<const float4*>(s0 + (long)(k + nsg) * n);
+        acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
+      }
+      if (k < splits) {
+        const float4 a = *reinterpret_cast<const float4*>(s0 + (long)k * n);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+      }
+      float* d = row + sg * plane + tap * LR + cl;
+      d[0] = acc.x; d[1] = acc.y; d[2] = acc.z; d[3] = acc.w;
     }
-    for (; k < splits; ++k) acc[0] += src[(long)k * n];
-    // fixed summation tree -> bitwise reproducible
-    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    float* dst = dw + ((long)co * CinReal + ci) * taps + tap;
-    *dst = accumulate ? (*dst + s) : s;
+  }
+  __syncthreads();
+  const int creal = min(CB, CinReal - c0);  // <= 0 for a chunk of padding channels only
+  float* __restrict__ out = dst.dw[member] + ((long)co * CinReal + c0) * taps;
+  for (int o = threadIdx.x; o < creal * taps; o += 256) {
+    const int ci = o / taps, tap = o - ci * taps;
+    float s = row[tap * LR + ci];
+    for (int g = 1; g < nsg; ++g) s += row[g * plane + tap * LR + ci];
+    out[o] = s;
   }
 }
 
@@ -391,7 +422,8 @@ int wgrad_patch_variant(const WgradParams& p, int dtype);
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy);
 int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t stream);
 
-int wgrad_plan(WgradParams& p, int dtype) {
+int wgrad_plan(WgradParams& p, int dtype, int group) {
+  D3F_CHECK(group >= 1 && group <= WG_MAXG, "wgrad: group of %d layers", group);
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "wgrad: bad dtype %d", dtype);
   const int ve = dtype == D3F_F32 ? 4 : 8;
   const long es = dtype == D3F_F32 ? 4 : 2;
@@ -406,6 +438,7 @@ int wgrad_plan(WgradParams& p, int dtype) {
   D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
   p.dy_bytes = (unsigned)bdy; p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1;
   p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
+  D3F_CHECK(group == 1 || (p.patch == 0 && p.C1 == 0), "wgrad: only plain single-source layers are grouped");
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
     int gx, gy;
     wgrad_patch_grid(p, p.patch, &gx, &gy);
@@ -417,7 +450,7 @@ int wgrad_plan(WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   p.tiles_co = cdiv(p.Cout, t.bm);
   p.tiles_ci = cdiv(cin, t.bn);
-  const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW;
+  const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW * group;
   const int total_chunks = cdiv(p.M, KP);
   long target = 1024;  // aim at ~4 blocks per CU
   if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
@@ -434,25 +467,40 @@ size_t wgrad_partial_floats(const WgradParams& p) {
   return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
 }
 
-template <typename T> static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream, bool x3) {
+template <typename T>
+static void wgrad_launch_t(const WgradParams& p, const WgradGroup& g, int bm, dim3 grid, hipStream_t stream, bool x3) {
   const dim3 block(256);
+  // Occupancy cap: unused dynamic LDS on top of the kernel's static tile.  The weight gradients run at the lowest
+  // priority NEXT to the dependent BatchNorm -> data-gradient chain; priority only decides which queue a FREE slot
+  // goes to, so if these workgroups fill every wave slot of every CU the chain's kernels wait for them to drain.
+  static const int lds_pad = getenv("D3F_WGRAD_LDS_PAD") ? atoi(getenv("D3F_WGRAD_LDS_PAD")) : 0;
   if (bm == 128) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
   } else if (bm == 64) {
     static const bool widen = getenv("D3F_BF16_WGRAD_F32") != nullptr;  // bf16 storage: old widening form (tuning knob)
     if (x3 || (sizeof(T) == 2 && !widen)) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, lds_pad, stream, p, g);
       return;
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, lds_pad, stream, p, g);
   }
 }
 
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+  WgradGroup g;
+  g.n = 1;
+  g.dy[0] = p.dy;
+  g.src0[0] = p.src0;
+  return wgrad_launch_group(p, g, dtype, stream);
+}
+
+int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hipStream_t stream) {
   if (p.M == 0) return 0;
+  D3F_CHECK(g.n >= 1 && g.n <= WG_MAXG, "wgrad: group of %d layers", g.n);
   if (p.patch) {
+    D3F_CHECK(g.n == 1 && g.dy[0] == p.dy && g.src0[0] == p.src0, "wgrad: the patch kernel takes one layer");
     const bool prof = prof_enabled(PROF_WGRAD);
     if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
     // (the persistent patch kernel of the narrow layers stays on the fp32 MFMA in f32x3 mode)
@@ -462,23 +510,31 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   }
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
-  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits);
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits, (unsigned)g.n);
   const bool prof = prof_enabled(PROF_WGRAD);
-  if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
-  if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, t.bm, grid, stream, false);
-  else wgrad_launch_t<float>(p, t.bm, grid, stream, dtype == D3F_F32X3);
+  if (prof) prof_begin(PROF_WGRAD, p.flops * g.n, stream);
+  if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, g, t.bm, grid, stream, false);
+  else wgrad_launch_t<float>(p, g, t.bm, grid, stream, dtype == D3F_F32X3);
   if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());
   return 0;
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
-                        int KH, int KW, float* dw, int accumulate, hipStream_t stream) {
-  const long n = (long)CoutP * KH * KW * Cin;
-  int blocks = cdiv(n, 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, splits, CoutP,
-                     Cout, Cin, CinReal, KH * KW, dw, accumulate);
+                        int KH, int KW, const WgradDst& dst, hipStream_t stream) {
+  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG && Cin % 4 == 0 && CinReal <= Cin && Cout <= CoutP, "wgrad reduce: arguments");
+  const int taps = KH * KW;
+  int cz = 1;  // channel chunks: enough workgroups to fill the chip, chunks of at least 16 channels (64-byte segments)
+  while ((long)Cout * dst.n * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
+  const int CB = Cin / cz, nvec = taps * CB / 4;
+  int nsg = nvec >= 256 ? 1 : 256 / nvec;  // slab groups: fill the 256 threads, every group gets >= 2 slabs
+  if (nsg > 8) nsg = 8;
+  while (nsg > 1 && 2 * nsg > splits) --nsg;
+  const int VB = nsg == 1 ? 256 : (nvec < 256 / nsg ? nvec : 256 / nsg);
+  const size_t lds = (size_t)nsg * taps * (CB + 1) * sizeof(float);
+  D3F_CHECK(lds <= 64 * 1024, "wgrad reduce: a %d-tap x %d-channel filter chunk exceeds the LDS tile", taps, CB);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)dst.n, (unsigned)cz), dim3(256), lds, stream,
+                     partial, splits, CoutP, Cin, CinReal, taps, CB, nsg, VB, dst);
   D3F_HIP(hipGetLastError());
   return 0;
 }

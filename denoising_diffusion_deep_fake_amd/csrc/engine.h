@@ -44,9 +44,18 @@ struct Unit {
   int CoutPad = 0, Kpad = 0, CinRows = 0, KpadD = 0, CoutD = 0;
   size_t coef_off = 0;  // bytes: mean[C] invstd[C] scale[C] shift[C] k[3C]
   int segment = 0;      // backward bucket this unit belongs to
+  size_t dy_off = 0;    // this unit's own dY buffer (kept until its weight-gradient group has run)
+  int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)
   ConvParams fwd{}, dgrad{};
   WgradParams wg{};
   int Cin() const { return C0 + C1; }
+};
+
+// Weight-gradient launch group: layers of identical shape inside one gradient bucket (the 3x3 stride-1
+// convolutions of a ResNet stage) whose weight gradients run as ONE launch once the LAST member's dY exists.
+struct WGroup {
+  std::vector<int> units;  // in backward order; the launch is issued behind units.back()
+  WgradParams wg{};        // planned for units.size() members
 };
 
 enum BwdKind { BW_HEAD, BW_UNIT, BW_SUM2X2, BW_POOL };
@@ -86,6 +95,7 @@ class UnetEngine {
   int predict_u8(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
                  const float mean[3], const float stdv[3], void* ws, int use_graph, hipStream_t s) const;
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
+  int export_shape(const char* name, int32_t dims[3]) const;
 
   std::vector<ParamInfo> params;
   std::vector<BnInfo> bns;
@@ -103,6 +113,7 @@ class UnetEngine {
   int wsize() const { return cdtype == D3F_F32X3 ? 6 : esize(); }  // bytes per packed weight (x3: three bf16 planes)
   int ve() const { return dtype == D3F_F32 ? 4 : 8; }
   int bke() const { return dtype == D3F_F32 ? 32 : 64; }
+  const TensorD* find_export(const char* name) const;
   int new_tensor(int H_, int W_, int C_);
   int new_grad(int tensor_id);
   size_t alloc(size_t bytes);
@@ -116,12 +127,14 @@ class UnetEngine {
   std::vector<int> grad_of;       // tensor id -> grad id or -1
   std::vector<bool> grad_init;    // plan-time: has a writer been emitted yet
   std::vector<BwdOp> bwd_ops;
+  std::vector<WGroup> wgroups;
   std::vector<int> fwd_order_;    // unit ids in execution order, -1 = max-pool
-  // backward concurrency: weight gradients run on a side stream next to the data-gradient / BN chain
+  // backward concurrency: weight gradients run on a side stream next to the data-gradient / BN chain.  Every unit
+  // keeps its own dY (585 MB at bs 16, 256x256: nothing next to 288 GB), so the side stream never holds the main
+  // chain back and a group's launch can wait for its last member.
   mutable hipStream_t side_ = nullptr;
-  static constexpr int NDY = 4;  // dY buffers: how far the side stream may lag behind the main chain
-  mutable hipEvent_t ev_dy_[NDY] = {}, ev_wg_[NDY] = {}, ev_join_ = nullptr;
-  mutable bool wg_pending_[NDY] = {};
+  mutable std::vector<hipEvent_t> ev_dy_;  // one per weight-gradient launch of a backward pass
+  mutable hipEvent_t ev_join_ = nullptr;
   // predict_u8 graph: private capture/launch stream + the pointers and constants the captured graph bakes in
   int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
   int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
@@ -132,10 +145,9 @@ class UnetEngine {
   mutable const void* gkey_[5] = {};
   mutable float gconst_[6] = {};
   size_t head_nchw_off = 0;
-  size_t dyn_off[NDY] = {};
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;
-  size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dy_off = 0, dz_off = 0, dfull_off = 0,
+  size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dz_off = 0, dfull_off = 0,
          wpart_off = 0, bsum_off = 0, splitk_off = 0;
   size_t stats_bytes = 0, bnpart_bytes = 0, dy_bytes = 0, dz_bytes = 0, dfull_bytes = 0, wpart_bytes = 0, splitk_bytes = 0;
 };

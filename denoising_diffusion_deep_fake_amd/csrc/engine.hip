@@ -7,6 +7,7 @@
 // smp-compatible state_dict keys.
 #include "engine.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -178,26 +179,36 @@ int UnetEngine::plan_unit(Unit& u) {
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = f.M;
   g.flops = 2.0 * macs;
-  if (int rc = wgrad_plan(g, dtype)) return rc;
+  if (int rc = wgrad_plan(g, dtype)) return rc;  // single-layer plan; identical layers are re-planned as a group in build()
   {
     const size_t wb = wgrad_partial_floats(g) * sizeof(float);
     if (wb > wpart_bytes) wpart_bytes = wb;
   }
+  u.dy_off = alloc(dyb);
 
   if (u.need_dgrad) {
     ConvParams& d = u.dgrad;
     std::memset(&d, 0, sizeof(d));
     const int s2 = u.stride == 2 ? 1 : 0;
-    d.B = B; d.Hv = u.Hv; d.Wv = u.Wv;  // extent of the (zero-inserted) dY == extent of dX
     D3F_CHECK(s2 || (u.Ho == u.Hv && u.Wo == u.Wv), "unit %s: dgrad expects a 'same' conv",
               u.conv_name.c_str());
-    d.C0 = u.CoutD; d.C1 = 0;
-    d.H0s = u.Ho; d.W0s = u.Wo; d.shift0 = s2; d.zi = s2;
-    d.Ho = u.Hv; d.Wo = u.Wv; d.Cout = u.Cin(); d.CoutPad = u.CinRows; d.Kpad = u.KpadD;
-    d.KH = u.KH; d.KW = u.KW; d.stride = 1; d.pad = u.KH - 1 - u.pad;
-    d.M = B * u.Hv * u.Wv;
+    d.B = B; d.C0 = u.CoutD; d.C1 = 0;
+    d.Cout = u.Cin(); d.CoutPad = u.CinRows; d.Kpad = u.KpadD;
     d.mode = CONV_DGRAD;
     d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
+    if (parity_dgrad_applies(dtype, u.stride, u.KH, u.pad, u.CoutD, u.C1)) {
+      // stride 2: four plain sub-convolutions over dY, one per output-parity class (conv_igemm.hip)
+      d.par = u.KH == 3 ? 1 : 2;
+      d.Hv = d.Ho = d.H0s = u.Ho; d.Wv = d.Wo = d.W0s = u.Wo;
+      d.KH = d.KW = u.KH == 3 ? 2 : 1; d.stride = 1; d.pad = 0;
+      d.M = B * u.Ho * u.Wo;
+    } else {
+      d.Hv = u.Hv; d.Wv = u.Wv;  // extent of the (zero-inserted) dY == extent of dX
+      d.H0s = u.Ho; d.W0s = u.Wo; d.shift0 = s2; d.zi = s2;
+      d.Ho = u.Hv; d.Wo = u.Wv;
+      d.KH = u.KH; d.KW = u.KW; d.stride = 1; d.pad = u.KH - 1 - u.pad;
+      d.M = B * u.Hv * u.Wv;
+    }
     if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
     if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
     d.flops = 2.0 * macs;
@@ -364,7 +375,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       BwdOp& pj = bwd_ops[j];
       if (!(pj.kind == BW_UNIT || pj.kind == BW_HEAD)) continue;
       const Unit& up = units[pj.unit];
-      if (!up.need_dgrad || pj.dst0_is_full_scratch || pj.dst1 >= 0 || pj.acc0 || pj.dst0 < 0) continue;
+      if (!up.need_dgrad || up.dgrad.par || pj.dst0_is_full_scratch || pj.dst1 >= 0 || pj.acc0 || pj.dst0 < 0) continue;
       BwdOp& ck = bwd_ops[j + 1];  // the consumer must be the very next op (bnpart is a stream-ordered scratch)
       if (ck.kind != BW_UNIT || ck.dA != pj.dst0 || writers(pj.dst0) != 1) continue;
       const Unit& uc = units[ck.unit];
@@ -377,12 +388,53 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
     }
   }
 
+  // ---- weight-gradient launch groups: identical plain layers of one bucket, in backward order ----------------
+  {
+    static const bool no_groups = getenv("D3F_NO_WGRAD_GROUPS") != nullptr;  // debugging knob: one launch per layer
+    // A group launches behind its LAST member, so a big group near the end of the backward pass leaves its work
+    // with nothing to overlap: the cap shrinks towards the end of the pass -- per encoder stage (512, 256, 128, 64
+    // output channels = the order the backward pass visits them).  Tuning knobs: D3F_WGRAD_GROUP_CAPS="a,b,c,d",
+    // D3F_WGRAD_GROUP_MAX=n (a cap on all of them).
+    int caps[4] = {5, 4, 2, 1};  // measured: equal step time to one launch per layer, fewer slabs
+    if (const char* gc = getenv("D3F_WGRAD_GROUP_CAPS")) sscanf(gc, "%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3]);
+    int group_max = WG_MAXG;
+    if (const char* gm = getenv("D3F_WGRAD_GROUP_MAX")) group_max = std::max(1, std::min(WG_MAXG, atoi(gm)));
+    auto cap_of = [&](const Unit& u) {
+      const int c = u.Cout >= 512 ? caps[0] : u.Cout >= 256 ? caps[1] : u.Cout >= 128 ? caps[2] : caps[3];
+      return std::max(1, std::min(group_max, c));
+    };
+    auto same = [](const Unit& a, const Unit& b) {
+      return a.segment == b.segment && a.Hv == b.Hv && a.Wv == b.Wv && a.C0 == b.C0 && a.C1 == 0 && b.C1 == 0 &&
+             a.up0 == 0 && b.up0 == 0 && a.CoutD == b.CoutD && a.Cout == b.Cout && a.CinReal == b.CinReal &&
+             a.KH == b.KH && a.stride == b.stride && a.pad == b.pad && a.wg.patch == 0 && b.wg.patch == 0;
+    };
+    for (const BwdOp& op : bwd_ops) {
+      if (op.kind != BW_UNIT && op.kind != BW_HEAD) continue;
+      Unit& u = units[op.unit];
+      int found = -1;
+      if (!no_groups)
+        for (size_t gi = 0; gi < wgroups.size() && found < 0; ++gi)
+          if ((int)wgroups[gi].units.size() < cap_of(u) && same(units[wgroups[gi].units[0]], u)) found = (int)gi;
+      if (found < 0) {
+        wgroups.emplace_back();
+        found = (int)wgroups.size() - 1;
+      }
+      wgroups[found].units.push_back(op.unit);
+      u.wgroup = found;
+    }
+    for (WGroup& g : wgroups) {
+      g.wg = units[g.units[0]].wg;
+      const int n = (int)g.units.size();
+      if (n > 1)
+        if (int rc = wgrad_plan(g.wg, dtype, n)) return rc;
+      const size_t wb = wgrad_partial_floats(g.wg) * n * sizeof(float);
+      if (wb > wpart_bytes) wpart_bytes = wb;
+    }
+  }
+
   // ---- scratch ------------------------------------------------------------------------
   stats_off = alloc(stats_bytes);
   bnpart_off = alloc(bnpart_bytes);
-  dy_off = alloc(dy_bytes);
-  dyn_off[0] = dy_off;  // ring of dY buffers: the side-stream wgrad of unit i reads one while later units write the others
-  for (int i = 1; i < NDY; ++i) dyn_off[i] = alloc(dy_bytes);
   dz_off = alloc(dz_bytes);
   dfull_off = alloc(dfull_bytes);
   wpart_off = alloc(wpart_bytes);
@@ -443,6 +495,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
     e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
     e.has_d = u.need_dgrad ? 1 : 0;
+    e.conv_stride = (u.need_dgrad && u.dgrad.par) ? 2 : 1;
     const int taps = u.KH * u.KW;
     D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
     int CT = 32;
@@ -611,30 +664,33 @@ UnetEngine::~UnetEngine() {
   if (ev_gin_) (void)hipEventDestroy(ev_gin_);
   if (ev_gout_) (void)hipEventDestroy(ev_gout_);
   if (gstream_) (void)hipStreamDestroy(gstream_);
-  for (int i = 0; i < NDY; ++i) {
-    if (ev_dy_[i]) (void)hipEventDestroy(ev_dy_[i]);
-    if (ev_wg_[i]) (void)hipEventDestroy(ev_wg_[i]);
-  }
+  for (hipEvent_t e : ev_dy_)
+    if (e) (void)hipEventDestroy(e);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (side_) (void)hipStreamDestroy(side_);
 }
 
-// Backward of segments [seg_begin, seg_end).  Per unit: BN backward (writes dY) -> {weight gradient,
+// Backward of segments [seg_begin, seg_end).  Per unit: BN backward (writes the unit's dY) -> {weight gradient,
 // data gradient}.  The two gradients are independent, and the following unit's BN-backward kernels are
-// HBM-bound while the weight gradient is MFMA-bound, so the weight gradient (+ its slab reduce) runs on
-// a side stream: main records "dY ready", side waits for it; dY is double-buffered and main waits for the
-// side-stream reader of a buffer before overwriting it; the side stream is joined before returning, so
-// after the call every gradient of the segment is final on the caller's stream.
+// HBM-bound while the weight gradient is MFMA-bound, so the weight gradients (+ their slab reduces) run on
+// a side stream: main records "dY ready", side waits for it.  Layers of identical shape share ONE weight-gradient
+// launch (WGroup), issued behind the group's last member; every unit owns its dY, so nothing on the main chain
+// ever waits for the side stream, which is joined before returning: after the call every gradient of the
+// segments is final on the caller's stream.
 int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
                          int seg_begin, int seg_end, hipStream_t s) const {
   char* ws = reinterpret_cast<char*>(ws_);
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
   static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob
-  // timing-only ablation (wrong gradients): D3F_ABLATE_BACKWARD contains w (skip weight gradients), d (data
-  // gradients), b (BatchNorm backward kernels) -- what each class costs on the critical path
+#ifdef D3F_PROFILING
+  // timing-only ablation (wrong gradients; profiling builds only): D3F_ABLATE_BACKWARD contains w (skip weight
+  // gradients), d (data gradients), b (BatchNorm backward kernels) -- what each class costs on the critical path
   static const char* abl = getenv("D3F_ABLATE_BACKWARD");
   const bool skip_w = abl && strchr(abl, 'w'), skip_d = abl && strchr(abl, 'd'), skip_b = abl && strchr(abl, 'b');
+#else
+  constexpr bool skip_w = false, skip_d = false, skip_b = false;
+#endif
   if (!serial && side_ == nullptr) {
     // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
     // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
@@ -644,17 +700,11 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
     D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
-    for (int i = 0; i < NDY; ++i) {
-      D3F_HIP(hipEventCreateWithFlags(&ev_dy_[i], hipEventDisableTiming));
-      D3F_HIP(hipEventCreateWithFlags(&ev_wg_[i], hipEventDisableTiming));
-    }
     D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
   hipStream_t ws_stream = serial ? s : side_;
-  char* dybuf[NDY];
-  for (int i = 0; i < NDY; ++i) dybuf[i] = ws + dyn_off[i];
   float* wpart = reinterpret_cast<float*>(ws + wpart_off);
-  int flip = 0;
+  size_t next_event = 0;
   bool side_used = false;
   for (const BwdOp& op : bwd_ops) {
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
@@ -671,13 +721,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
     const Unit& u = units[op.unit];
     const long rows = (long)B * u.Ho * u.Wo;
-    const int cur = flip;
-    flip = (flip + 1) % NDY;
-    char* dy = dybuf[cur];
-    if (!serial && wg_pending_[cur]) {  // the wgrad that read this buffer two units ago must be done
-      D3F_HIP(hipStreamWaitEvent(s, ev_wg_[cur], 0));
-      wg_pending_[cur] = false;
-    }
+    char* dy = ws + u.dy_off;
     if (op.kind == BW_HEAD) {
       if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s)) return rc;
       if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
@@ -704,35 +748,46 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         return rc;
       }
       if (!skip_b)
-      if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
-                                          grads + u.g_off, grads + u.b_off, 0, k, s))
-        return rc;
+        if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
+                                            grads + u.g_off, grads + u.b_off, 0, k, s))
+          return rc;
       if (!skip_b)
-      if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
-                                       op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
-                                       u.Cout, s, msc, msf))
+        if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
+                                         op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
+                                         u.Cout, s, msc, msf))
+          return rc;
+    }
+    // weight gradient of the unit's launch group (side stream), once the group's last dY exists
+    const WGroup& grp = wgroups[u.wgroup];
+    if (grp.units.back() == op.unit && !skip_w) {
+      if (!serial) {
+        if (next_event == ev_dy_.size()) {
+          hipEvent_t e = nullptr;
+          D3F_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          ev_dy_.push_back(e);
+        }
+        D3F_HIP(hipEventRecord(ev_dy_[next_event], s));
+        D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[next_event], 0));
+        ++next_event;
+        side_used = true;
+      }
+      WgradParams g = grp.wg;
+      WgradGroup gp;
+      WgradDst gd;
+      gp.n = gd.n = (int)grp.units.size();
+      for (int i = 0; i < gp.n; ++i) {
+        const Unit& m = units[grp.units[i]];
+        gp.dy[i] = ws + m.dy_off;
+        gp.src0[i] = T(m.in0);
+        gd.dw[i] = grads + m.w_off;
+      }
+      g.dy = gp.dy[0];
+      g.src0 = gp.src0[0];
+      g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;  // two-source layers are never grouped
+      g.partial = wpart;
+      if (int rc = wgrad_launch_group(g, gp, cdtype, ws_stream)) return rc;
+      if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
         return rc;
-    }
-    // weight gradient (side stream)
-    if (!serial) {
-      D3F_HIP(hipEventRecord(ev_dy_[cur], s));
-      D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[cur], 0));
-    }
-    WgradParams g = u.wg;
-    g.dy = dy;
-    g.src0 = T(u.in0);
-    g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
-    g.partial = wpart;
-    if (!skip_w)
-    if (int rc = wgrad_launch(g, cdtype, ws_stream)) return rc;
-    if (!skip_w)
-    if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW,
-                                     grads + u.w_off, 0, ws_stream))
-      return rc;
-    if (!serial) {
-      D3F_HIP(hipEventRecord(ev_wg_[cur], side_));
-      wg_pending_[cur] = true;
-      side_used = true;
     }
     // data gradient (main stream)
     if (u.need_dgrad && !skip_d) {
@@ -749,6 +804,8 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
       d.acc1 = op.acc1 ? 1 : 0;
       d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+      if (d.par == 2 && !d.acc0)  // 1x1 stride 2: only even pixels receive a gradient; the others are zero
+        D3F_HIP(hipMemsetAsync(d.out0, 0, (size_t)4 * d.M * d.Cout * esize(), s));
       if (op.fuse_for_unit >= 0) {
         const Unit& uc = units[op.fuse_for_unit];
         d.bn_y = T(uc.y);
@@ -761,29 +818,38 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream
     D3F_HIP(hipEventRecord(ev_join_, side_));
     D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
-    for (int i = 0; i < NDY; ++i) wg_pending_[i] = false;
   }
   return 0;
 }
 
-int UnetEngine::export_tensor(const char* name, const void* ws_, float* out_nchw, hipStream_t s) const {
-  const char* ws = reinterpret_cast<const char*>(ws_);
+// "<conv name>:y" raw conv output, ":a" post BN(+residual)+ReLU activation, ":da" gradient w.r.t. that activation
+const TensorD* UnetEngine::find_export(const char* name) const {
   const std::string n(name);
   const size_t colon = n.rfind(':');
-  D3F_CHECK(colon != std::string::npos, "export: name must look like '<conv>:y|a|da'");
+  if (colon == std::string::npos) return nullptr;
   const std::string un = n.substr(0, colon), kind = n.substr(colon + 1);
+  if (kind != "y" && kind != "a" && kind != "da") return nullptr;
   for (const Unit& u : units) {
     if (u.conv_name != un) continue;
-    int tid = kind == "y" ? u.y : u.a;
-    D3F_CHECK(tid >= 0, "export: unit %s has no tensor '%s'", un.c_str(), kind.c_str());
-    const TensorD* t = &tensors[tid];
-    if (kind == "da") {
-      D3F_CHECK(grad_of[tid] >= 0, "export: no gradient tensor for %s", un.c_str());
-      t = &gtensors[grad_of[tid]];
-    }
-    return nhwc_to_nchw_launch(dtype, ws + t->off, out_nchw, B, t->C, t->H, t->W, t->C, s);
+    const int tid = kind == "y" ? u.y : u.a;
+    if (tid < 0) return nullptr;
+    if (kind == "da") return grad_of[tid] >= 0 ? &gtensors[grad_of[tid]] : nullptr;
+    return &tensors[tid];
   }
-  return set_error(-1, "export: no unit named %s", un.c_str());
+  return nullptr;
+}
+
+int UnetEngine::export_tensor(const char* name, const void* ws_, float* out_nchw, hipStream_t s) const {
+  const TensorD* t = find_export(name);
+  D3F_CHECK(t != nullptr, "export: no tensor named '%s' (expected '<conv name>:y|a|da')", name);
+  return nhwc_to_nchw_launch(dtype, reinterpret_cast<const char*>(ws_) + t->off, out_nchw, B, t->C, t->H, t->W, t->C, s);
+}
+
+int UnetEngine::export_shape(const char* name, int32_t dims[3]) const {
+  const TensorD* t = find_export(name);
+  D3F_CHECK(t != nullptr, "export: no tensor named '%s' (expected '<conv name>:y|a|da')", name);
+  dims[0] = t->C; dims[1] = t->H; dims[2] = t->W;
+  return 0;
 }
 
 }  // namespace d3f

@@ -77,7 +77,7 @@ int affine_warp_launch(const float* in, const float* theta, float* out, int B, i
 // PyTorch [Cout][CinReal][KH][KW] fp32 -> forward pack [CoutPad][Kpad] (k = tap*Cin + c) and/or
 // data-gradient pack [CinPadRows][KpadD] (k = flipped tap*Cout + co); T = dtype.
 int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Cin, int KH, int KW,
-                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
+                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD, int stride,
                         hipStream_t stream);
 
 // every layer of a network in one launch (engine): table passed by value as a kernel argument
@@ -88,6 +88,7 @@ struct PackEntry {
   uint32_t wf_off16, wd_off16;  // 16-byte units into the workspace
   uint32_t block0;              // first block of this layer; blocks are (filter tile, channel tile)
   uint16_t Cout, CinReal, Cin, taps, CoutPad, Kpad, CinRows, CoutD, KpadD, has_d, CT, ctiles;
+  uint16_t conv_stride;         // 2: data-gradient taps stored parity class by class (dgrad_tap_slot_to_flipped)
 };
 struct PackTable {
   int n;

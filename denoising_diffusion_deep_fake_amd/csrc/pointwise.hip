@@ -154,41 +154,60 @@ int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* run
   return 0;
 }
 
+// Grid-stride with a stride of gridDim * 256 vectors; 256 * N elements are a multiple of every channel count here
+// (C is a power of two <= 1024, checked by the launcher), so a thread sees ONE channel group for its whole life:
+// the per-channel coefficients are loaded once, outside the loop (they were 2-8 extra global loads per 16-byte data
+// load), and two vectors are in flight per trip.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const T* __restrict__ res, const T* __restrict__ yr, const float* __restrict__ scale_r,
     const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C) {
   constexpr int N = V16<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c0 = (int)((i * N) % C);
-    float v[N], sc[N], sf[N];
-    V16<T>::load(y + i * N, v);
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  const int c0 = (int)((i0 * N) % C);
+  float sc[N], sf[N], scr[N], sfr[N];
 #pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(scale + c0 + k);
-      const float4 b = *reinterpret_cast<const float4*>(shift + c0 + k);
-      sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
-      sf[k] = b.x; sf[k + 1] = b.y; sf[k + 2] = b.z; sf[k + 3] = b.w;
-    }
+  for (int k = 0; k < N; ++k) {
+    sc[k] = scale[c0 + k];
+    sf[k] = shift[c0 + k];
+    scr[k] = yr != nullptr ? scale_r[c0 + k] : 0.f;
+    sfr[k] = yr != nullptr ? shift_r[c0 + k] : 0.f;
+  }
+  const T* __restrict__ radd = res != nullptr ? res : yr;
+  auto finish = [&](long i, float (&v)[N], const float (&r)[N]) {
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = v[k] * sc[k] + sf[k];
     if (res != nullptr) {
-      float r[N];
-      V16<T>::load(res + i * N, r);
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] += r[k];
     } else if (yr != nullptr) {
-      float r[N];
-      V16<T>::load(yr + i * N, r);
 #pragma unroll
-      for (int k = 0; k < N; ++k) v[k] += r[k] * scale_r[c0 + k] + shift_r[c0 + k];
+      for (int k = 0; k < N; ++k) v[k] += r[k] * scr[k] + sfr[k];
     }
     if (relu) {
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
     }
     V16<T>::store(out + i * N, v);
+  };
+  long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {
+    float v0[N], v1[N], r0[N] = {}, r1[N] = {};
+    V16<T>::load(y + i * N, v0);
+    V16<T>::load(y + (i + stride) * N, v1);
+    if (radd != nullptr) {
+      V16<T>::load(radd + i * N, r0);
+      V16<T>::load(radd + (i + stride) * N, r1);
+    }
+    finish(i, v0, r0);
+    finish(i + stride, v1, r1);
+  }
+  if (i < nvec) {
+    float v0[N], r0[N] = {};
+    V16<T>::load(y + i * N, v0);
+    if (radd != nullptr) V16<T>::load(radd + i * N, r0);
+    finish(i, v0, r0);
   }
 }
 
@@ -196,7 +215,7 @@ int bn_apply_launch(int dtype, const void* y, const float* scale, const float* s
                     const void* res, const void* yr, const float* scale_r, const float* shift_r,
                     int relu, void* out, long rows, int C, hipStream_t stream) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
-  D3F_CHECK(C % ve == 0, "bn_apply: C=%d not a multiple of %d", C, ve);
+  D3F_CHECK(C % ve == 0 && (256 * ve) % C == 0, "bn_apply: C=%d must divide %d", C, 256 * ve);
   const long nvec = rows * C / ve;
   if (nvec == 0) return 0;
   const int grid = grid_for(nvec);
@@ -363,6 +382,8 @@ int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
   return 0;
 }
 
+// (same thread <-> channel-group invariance as bn_apply_kernel: the seven per-channel coefficient vectors are loaded
+// once per thread, two data vectors are in flight per trip)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
@@ -370,36 +391,70 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C,
     const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
   constexpr int N = V16<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c0 = (int)((i * N) % C);
-    float g[N], yy[N], o[N];
-    V16<T>::load(dA + i * N, g);
-    V16<T>::load(y + i * N, yy);
-    if (mask_scale != nullptr) {
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  const int c0 = (int)((i0 * N) % C);
+  float mu[N], is[N], k0[N], k1[N], k2[N], msc[N], msf[N];
 #pragma unroll
-      for (int k = 0; k < N; ++k) g[k] = (yy[k] * mask_scale[c0 + k] + mask_shift[c0 + k]) > 0.f ? g[k] : 0.f;
-    } else if (a != nullptr) {
-      float aa[N];
-      V16<T>::load(a + i * N, aa);
+  for (int k = 0; k < N; ++k) {
+    const int c = c0 + k;
+    mu[k] = mean[c];
+    is[k] = invstd[c];
+    k0[k] = coef[c];
+    k1[k] = coef[C + c];
+    k2[k] = coef[2 * C + c];
+    msc[k] = mask_scale != nullptr ? mask_scale[c] : 0.f;
+    msf[k] = mask_scale != nullptr ? mask_shift[c] : 0.f;
+  }
+  const bool from_y = mask_scale != nullptr, from_a = !from_y && a != nullptr;
+  const bool racc = dres != nullptr && dres_acc;
+  auto finish = [&](long i, float (&g)[N], const float (&yy)[N], const float (&aa)[N], const float (&d)[N]) {
+    float o[N];
+    if (from_y) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
+    } else if (from_a) {
 #pragma unroll
       for (int k = 0; k < N; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const int c = c0 + k;
-      const float xhat = (yy[k] - mean[c]) * invstd[c];
-      o[k] = coef[c] * (g[k] - coef[C + c] - xhat * coef[2 * C + c]);
+      const float xhat = (yy[k] - mu[k]) * is[k];
+      o[k] = k0[k] * (g[k] - k1[k] - xhat * k2[k]);
     }
     V16<T>::store(dy + i * N, o);
     if (dres != nullptr) {
-      if (dres_acc) {
-        float d[N];
-        V16<T>::load(dres + i * N, d);
+      if (racc) {
 #pragma unroll
         for (int k = 0; k < N; ++k) g[k] += d[k];
       }
       V16<T>::store(dres + i * N, g);
     }
+  };
+  long i = i0;
+  for (; i + stride < nvec; i += 2 * stride) {
+    float g0[N], g1[N], y0[N], y1[N], a0[N] = {}, a1[N] = {}, d0[N] = {}, d1[N] = {};
+    V16<T>::load(dA + i * N, g0);
+    V16<T>::load(dA + (i + stride) * N, g1);
+    V16<T>::load(y + i * N, y0);
+    V16<T>::load(y + (i + stride) * N, y1);
+    if (from_a) {
+      V16<T>::load(a + i * N, a0);
+      V16<T>::load(a + (i + stride) * N, a1);
+    }
+    if (racc) {
+      V16<T>::load(dres + i * N, d0);
+      V16<T>::load(dres + (i + stride) * N, d1);
+    }
+    finish(i, g0, y0, a0, d0);
+    finish(i + stride, g1, y1, a1, d1);
+  }
+  if (i < nvec) {
+    float g0[N], y0[N], a0[N] = {}, d0[N] = {};
+    V16<T>::load(dA + i * N, g0);
+    V16<T>::load(y + i * N, y0);
+    if (from_a) V16<T>::load(a + i * N, a0);
+    if (racc) V16<T>::load(dres + i * N, d0);
+    finish(i, g0, y0, a0, d0);
   }
 }
 
@@ -408,7 +463,7 @@ int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y,
                         long rows, int C, hipStream_t stream, const float* mask_scale,
                         const float* mask_shift) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
-  D3F_CHECK(C % ve == 0, "bn_bwd_apply: C=%d", C);
+  D3F_CHECK(C % ve == 0 && (256 * ve) % C == 0, "bn_bwd_apply: C=%d must divide %d", C, 256 * ve);
   const long nvec = rows * C / ve;
   if (nvec == 0) return 0;
   const int grid = grid_for(nvec);
@@ -764,7 +819,14 @@ int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int
 // weight packing (fp32 master in PyTorch layout -> kernel layouts)
 // ------------------------------------------------------------------------------------------
 // forward:  wf[n][(kh*KW + kw)*Cin + c]                     = w[n][c][kh][kw]
-// dgrad:    wd[c][((KH-1-kh)*KW + (KW-1-kw))*CoutD + n]     = w[n][c][kh][kw]
+// dgrad:    wd[c][slot*CoutD + n]                            = w[n][c][kh][kw], flipped tap f = (KH-1-kh)*KW + (KW-1-kw)
+//           stride 1: slot = f.  3x3 stride 2: the flipped taps are stored output-parity class by class,
+//           (odd,odd) (odd,even) (even,odd) (even,even) = f in {0,2,6,8} {1,7} {3,5} {4}, so that each class of the
+//           parity-decomposed data gradient (conv_igemm.hip) is one contiguous k-range of the same rows.
+__device__ __forceinline__ int dgrad_tap_slot_to_flipped(int slot, int taps, int stride) {
+  if (stride == 2 && taps == 9) return (int)((0x453718620ull >> (4 * slot)) & 15);  // 0,2,6,8,1,7,3,5,4
+  return slot;
+}
 // store one packed weight: plain T, or (X3) its exact 3-way bf16 split into three planes `plane` elements apart
 template <typename T, bool X3>
 __device__ __forceinline__ void pack_store(T* __restrict__ base, long idx, long plane, float v) {
@@ -786,7 +848,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
                                                            int CinReal, int Cin, int KH, int KW,
                                                            T* __restrict__ wf, int CoutPad, int Kpad,
                                                            T* __restrict__ wd, int CinRows, int CoutD,
-                                                           int KpadD) {
+                                                           int KpadD, int stride) {
   const int taps = KH * KW;
   const long nf = wf ? (long)CoutPad * Kpad : 0;
   const long nd = wd ? (long)CinRows * KpadD : 0;
@@ -800,16 +862,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     } else {
       const long j = i - nf;
       const int c = (int)(j / KpadD), k = (int)(j % KpadD);
-      const int tapf = k / CoutD, n = k % CoutD;
+      const int slot = k / CoutD, n = k % CoutD;
       float v = 0.f;
-      if (c < CinReal && tapf < taps && n < Cout) v = w[((long)n * CinReal + c) * taps + (taps - 1 - tapf)];
+      if (c < CinReal && slot < taps && n < Cout)
+        v = w[((long)n * CinReal + c) * taps + (taps - 1 - dgrad_tap_slot_to_flipped(slot, taps, stride))];
       pack_store<T, X3>(wd, j, nd, v);
     }
   }
 }
 
 int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Cin, int KH, int KW,
-                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD,
+                        void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD, int stride,
                         hipStream_t stream) {
   const int ve = dtype == D3F_BF16 ? 8 : 4;
   const int CoutD = (int)round_up(Cout, ve);
@@ -819,13 +882,13 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
   D3F_CHECK(!wd || KpadD >= KH * KW * CoutD, "pack: KpadD");
   if (dtype == D3F_F32)
     hipLaunchKernelGGL((pack_weights_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
-                       CinReal, Cin, KH, KW, (float*)wf, CoutPad, Kpad, (float*)wd, CinRows, CoutD, KpadD);
+                       CinReal, Cin, KH, KW, (float*)wf, CoutPad, Kpad, (float*)wd, CinRows, CoutD, KpadD, stride);
   else if (dtype == D3F_F32X3)
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
-                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
+                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD, stride);
   else
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout,
-                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD);
+                       CinReal, Cin, KH, KW, (bf16_t*)wf, CoutPad, Kpad, (bf16_t*)wd, CinRows, CoutD, KpadD, stride);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -877,11 +940,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
   if (e.has_d) {
     for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
-      const int nl = i % PACK_NT, tapf = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
+      const int nl = i % PACK_NT, slot = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
       const int n = n0 + nl, c = c0 + cl;
       if (c < CinRows && n < CoutD)
-        pack_store<T, X3>(wd, (long)c * KpadD + tapf * CoutD + n, (long)CinRows * KpadD,
-                          tile[nl * stride + cl * taps + (taps - 1 - tapf)]);
+        pack_store<T, X3>(wd, (long)c * KpadD + slot * CoutD + n, (long)CinRows * KpadD,
+                          tile[nl * stride + cl * taps + (taps - 1 - dgrad_tap_slot_to_flipped(slot, taps, e.conv_stride))]);
     }
     if (nt == 0) {
       const int k0 = taps * CoutD, tail = KpadD - k0;

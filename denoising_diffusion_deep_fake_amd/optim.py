@@ -18,7 +18,11 @@ from .unet import Unet
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, module=None, grad_scale=1.0):
         params = list(params)
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the param-group keys of torch.optim.Adam, so that its load_state_dict accepts a state_dict saved here (and
+        # the other way round); the variants behind the switches are not implemented by the one-launch update
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         if not isinstance(module, Unet):
             raise TypeError("FusedAdam needs module=<the d3f Unet that owns these parameters>")
         if [id(p) for p in params] != [id(p) for p in module.parameters()]:
@@ -53,6 +57,9 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
         g = self.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise NotImplementedError("FusedAdam implements plain Adam (weight_decay=0, amsgrad=False, maximize=False), "
+                                      "which is what the reference configures")
         self._step += 1
         ops.adam_step(flat, grads, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
                       float(g["betas"][1]), float(g["eps"]), self._step, float(self.grad_scale))

@@ -370,6 +370,7 @@ class Unet(nn.Module):
         self._pack_if_needed(eng)
         out = torch.empty((x.shape[0], self.classes, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
         eng.serial += 1
+        rt["last_engine"] = eng
         check(_lib.lib().d3f_unet_forward(eng.h, ptr(rt["flat"]), ptr(rt["flat_bn"]), ptr(x), ptr(out),
                                           ptr(eng.workspace), 1 if training else 0, stream_ptr()))
         if training:
@@ -468,6 +469,25 @@ class Unet(nn.Module):
                                              ptr(eng.workspace), 1 if graph else 0, stream_ptr()))
         eng.keep = (x, out)  # the captured graph bakes these pointers in: keep them alive with the engine
         return out[0] if single else out
+
+    def export_activation(self, name):
+        """debugging / parity tests: an internal tensor of the MOST RECENT forward (+ backward) as NCHW f32 --
+        "<conv name>:y" raw conv output, ":a" post BatchNorm(+residual)+ReLU activation, ":da" gradient w.r.t. that
+        activation (d3f_unet_export).  Channels beyond the real count (vector padding) are cut off by the caller."""
+        eng = self._rt.get("last_engine")
+        if eng is None:
+            raise D3FError("export_activation() before any forward pass")
+        out = torch.empty(self.export_activation_shape(name), dtype=torch.float32, device=eng.workspace.device)
+        check(_lib.lib().d3f_unet_export(eng.h, name.encode(), ptr(eng.workspace), ptr(out), stream_ptr()))
+        return out
+
+    def export_activation_shape(self, name):
+        eng = self._rt.get("last_engine")
+        if eng is None:
+            raise D3FError("export_activation_shape() before any forward pass")
+        dims = (C.c_int32 * 3)()
+        check(_lib.lib().d3f_unet_export_shape(eng.h, name.encode(), dims))
+        return (eng.shape[0], dims[0], dims[1], dims[2])
 
     # flops of the conv contractions of one call (2*MAC), for roofline reporting
     def conv_flops(self, B, H, W, device=None):

@@ -106,6 +106,8 @@ int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, 
 /* debugging / tests: copy an internal activation ("<conv name>:y" raw conv output, ":a" post
  * BN+ReLU, ":da" its gradient) to NCHW f32 */
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream);
+/* extent of that tensor: dims = {channels (as stored: padded to the vector width), height, width} */
+int d3f_unet_export_shape(d3f_unet_t h, const char* name, int32_t dims[3]);
 
 /* ---------------------------------------------------------------------------------------
  * Single operators (the kernels the network is made of; used by the parity tests)

@@ -7,8 +7,10 @@ rel-L2 <= 4e-3 for forward / data gradient (measured 1.7e-3), <= 1e-5 for the f3
 (measured 1e-7).  Whole network: this BatchNorm-heavy net amplifies rounding ~100x (f32: 7e-6 forward
 error from 6e-8 rounding); with 2^-8 activation rounding the measured distance to the f32 CPU oracle is
 6.7e-2 / 7.5e-2 rel-L2 forward (B=4 64x64 / B=8 128x128), loss within 3e-4, flat-gradient cosine 0.80 /
-0.88.  Gates: forward rel-L2 <= 0.15, |loss - oracle| <= 2e-3, gradient cosine >= 0.6 -- bf16 is a
-throughput mode, the f32 path is the parity-graded one (tests/test_gpu_unet.py)."""
+0.88.  Gates = those measurements with 1.5x head-room: forward rel-L2 <= 0.11, |loss - oracle| <= 5e-4, gradient
+cosine >= 0.72 (a dropped layer or a wrong operand plane is far outside).  bf16 is a throughput mode, the f32 path
+is the parity-graded one (tests/test_gpu_unet.py, tests/test_gpu_parity_layers.py); full-size bf16 properties:
+tests/test_gpu_fullsize.py."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -85,11 +87,12 @@ def test_unet_bf16_training_step():
     lossv, gp = ops.mse_ssim_loss(pred.detach(), x.cuda())
     pred.backward(gp)
     assert pred.dtype == torch.float32            # boundary tensors stay f32
-    assert rel_l2(pred, pr) < 0.15
-    assert abs(lossv[0].item() - lr.item()) < 2e-3
+    # gates = what was measured (6.7e-2 / 7.5e-2 forward, |dloss| 3e-4, cosine 0.80 / 0.88) with 1.5x head-room
+    assert rel_l2(pred, pr) < 0.11
+    assert abs(lossv[0].item() - lr.item()) < 5e-4
     g32 = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     cos = F.cosine_similarity(net.flat_grads.cpu().double(), g32.double(), dim=0).item()
-    assert cos > 0.6, cos
+    assert cos > 0.72, cos
     assert torch.isfinite(net.flat_grads).all()
     net.eval()
     ref.eval()

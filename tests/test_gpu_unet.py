@@ -360,7 +360,8 @@ def test_two_forwards_before_backward_and_no_grad_in_between():
     total = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     assert rel_l2(total, ga + gb) < 1e-6
     pool = next(iter(net._rt["engines"].values()))
-    assert len(pool) == 2 and not any(e.in_use for e in pool)
+    # two leased workspaces + one for the no_grad pass that ran while both were leased
+    assert len(pool) == 3 and not any(e.in_use for e in pool)
     # a graph that is dropped without backward gives its workspace back
     y = net(x1)
     assert sum(e.in_use for e in pool) == 1
