@@ -925,28 +925,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 constexpr int SK_ROWS = 8;   // rows per reduce workgroup (small: the reduce is latency-bound, it wants many workgroups)
 constexpr int SK_MAX = 8;    // upper bound of splitk (plan)
 
-// 16-byte stores of 4 consecutive channels (4 f32, or 4 bf16 as 8 bytes)
-template <typename T> __device__ __forceinline__ void sk_store4(T* dst, const float (&v)[4]);
-template <> __device__ __forceinline__ void sk_store4<float>(float* dst, const float (&v)[4]) {
-  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void sk_store4<bf16_t>(bf16_t* dst, const float (&v)[4]) {
-  uint2 w;
-  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  *reinterpret_cast<uint2*>(dst) = w;
-}
-template <typename T> __device__ __forceinline__ void sk_load4(const T* src, float (&v)[4]);
-template <> __device__ __forceinline__ void sk_load4<float>(const float* src, float (&v)[4]) {
-  const float4 t = *reinterpret_cast<const float4*>(src);
-  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-template <> __device__ __forceinline__ void sk_load4<bf16_t>(const bf16_t* src, float (&v)[4]) {
-  const uint2 w = *reinterpret_cast<const uint2*>(src);
-  v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
-  v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
   __shared__ float red[256 * 4 * 2];
@@ -956,26 +934,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int m_begin = blockIdx.x * SK_ROWS;
   const int m_end = min(m_begin + SK_ROWS, p.M);
   const long MN = (long)p.M * p.Cout;
-  const int n = cv * 4;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
   T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
-  // per-channel coefficients of this thread's four channels: loaded once (a thread keeps its vector column)
-  float c_sc[4] = {}, c_sf[4] = {}, c_mu[4] = {}, c_is[4] = {};
-  const bool fused_bn = p.mode == CONV_DGRAD && p.bn_partial != nullptr;
-  if (p.mode == CONV_EVAL_FUSED) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { c_sc[k] = p.scale[n + k]; c_sf[k] = p.shift[n + k]; }
-  } else if (fused_bn) {
-    const int C = p.Cout;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c_mu[k] = p.bn_coef[n + k]; c_is[k] = p.bn_coef[C + n + k];
-      c_sc[k] = p.bn_coef[2 * C + n + k]; c_sf[k] = p.bn_coef[3 * C + n + k];
-    }
-  }
   for (int m = m_begin + r0; m < m_end; m += RP) {
-    const long e = (long)m * p.Cout + n;
+    const long e = (long)m * p.Cout + cv * 4;
     // all slabs in flight at once (splitk is wave-uniform: scalar branches), summed in slab order
     float4 w[SK_MAX];
 #pragma unroll
@@ -991,42 +954,43 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
       for (int k = 0; k < 4; ++k) {
         s1[k] += vv[k];
         s2[k] += vv[k] * vv[k];
+        o0[e + k] = from_f32<T>(vv[k]);
       }
-      sk_store4<T>(o0 + e, vv);
     } else if (p.mode == CONV_EVAL_FUSED) {  // folded BatchNorm (+ residual) (+ ReLU), as the fused epilogue
-      float r[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.res != nullptr) sk_load4<T>(reinterpret_cast<const T*>(p.res) + e, r);
+      const int n = cv * 4;
+      const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float x = vv[k] * c_sc[k] + c_sf[k];
-        if (p.res != nullptr) x += r[k];
+        float x = vv[k] * p.scale[n + k] + p.shift[n + k];
+        if (res != nullptr) x += to_f32<T>(res[e + k]);
         if (p.relu) x = fmaxf(x, 0.f);
-        vv[k] = x;
+        o0[e + k] = from_f32<T>(x);
       }
-      sk_store4<T>(o0 + e, vv);
     } else {  // CONV_DGRAD
+      const int n = cv * 4;
       const bool first = n < p.out_c0;
       T* __restrict__ dst = first ? o0 + (long)m * p.out_c0 + n : o1 + (long)m * (p.Cout - p.out_c0) + (n - p.out_c0);
       const bool accum = first ? p.acc0 : p.acc1;
-      if (fused_bn) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel): on the RAW sum
-        float yy[4];
-        sk_load4<T>(reinterpret_cast<const T*>(p.bn_y) + e, yy);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = vv[k];
+        if (accum) x += to_f32<T>(dst[k]);
+        dst[k] = from_f32<T>(x);
+      }
+      if (p.bn_partial != nullptr) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel)
+        const int C = p.Cout;
+        const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float g = (yy[k] * c_sc[k] + c_sf[k]) > 0.f ? vv[k] : 0.f;
+          const float yy = to_f32<T>(yb[e + k]);
+          const float g = (yy * p.bn_coef[2 * C + n + k] + p.bn_coef[3 * C + n + k]) > 0.f ? vv[k] : 0.f;
           s1[k] += g;
-          s2[k] += g * ((yy[k] - c_mu[k]) * c_is[k]);
+          s2[k] += g * ((yy - p.bn_coef[n + k]) * p.bn_coef[C + n + k]);
         }
       }
-      if (accum) {
-        float o[4];
-        sk_load4<T>(dst, o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] += o[k];
-      }
-      sk_store4<T>(dst, vv);
     }
   }
+  const bool fused_bn = p.mode == CONV_DGRAD && p.bn_partial != nullptr;
   if ((p.mode == CONV_RAW_STATS && p.stats != nullptr) || fused_bn) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

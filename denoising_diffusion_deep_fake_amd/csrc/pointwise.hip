@@ -154,60 +154,41 @@ int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* run
   return 0;
 }
 
-// Grid-stride with a stride of gridDim * 256 vectors; 256 * N elements are a multiple of every channel count here
-// (C is a power of two <= 1024, checked by the launcher), so a thread sees ONE channel group for its whole life:
-// the per-channel coefficients are loaded once, outside the loop (they were 2-8 extra global loads per 16-byte data
-// load), and two vectors are in flight per trip.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const T* __restrict__ res, const T* __restrict__ yr, const float* __restrict__ scale_r,
     const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C) {
   constexpr int N = V16<T>::N;
-  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-  const int c0 = (int)((i0 * N) % C);
-  float sc[N], sf[N], scr[N], sfr[N];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float v[N], sc[N], sf[N];
+    V16<T>::load(y + i * N, v);
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    sc[k] = scale[c0 + k];
-    sf[k] = shift[c0 + k];
-    scr[k] = yr != nullptr ? scale_r[c0 + k] : 0.f;
-    sfr[k] = yr != nullptr ? shift_r[c0 + k] : 0.f;
-  }
-  const T* __restrict__ radd = res != nullptr ? res : yr;
-  auto finish = [&](long i, float (&v)[N], const float (&r)[N]) {
+    for (int k = 0; k < N; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(scale + c0 + k);
+      const float4 b = *reinterpret_cast<const float4*>(shift + c0 + k);
+      sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
+      sf[k] = b.x; sf[k + 1] = b.y; sf[k + 2] = b.z; sf[k + 3] = b.w;
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = v[k] * sc[k] + sf[k];
     if (res != nullptr) {
+      float r[N];
+      V16<T>::load(res + i * N, r);
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] += r[k];
     } else if (yr != nullptr) {
+      float r[N];
+      V16<T>::load(yr + i * N, r);
 #pragma unroll
-      for (int k = 0; k < N; ++k) v[k] += r[k] * scr[k] + sfr[k];
+      for (int k = 0; k < N; ++k) v[k] += r[k] * scale_r[c0 + k] + shift_r[c0 + k];
     }
     if (relu) {
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k], 0.f);
     }
     V16<T>::store(out + i * N, v);
-  };
-  long i = i0;
-  for (; i + stride < nvec; i += 2 * stride) {
-    float v0[N], v1[N], r0[N] = {}, r1[N] = {};
-    V16<T>::load(y + i * N, v0);
-    V16<T>::load(y + (i + stride) * N, v1);
-    if (radd != nullptr) {
-      V16<T>::load(radd + i * N, r0);
-      V16<T>::load(radd + (i + stride) * N, r1);
-    }
-    finish(i, v0, r0);
-    finish(i + stride, v1, r1);
-  }
-  if (i < nvec) {
-    float v0[N], r0[N] = {};
-    V16<T>::load(y + i * N, v0);
-    if (radd != nullptr) V16<T>::load(radd + i * N, r0);
-    finish(i, v0, r0);
   }
 }
 
@@ -382,8 +363,6 @@ int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
   return 0;
 }
 
-// (same thread <-> channel-group invariance as bn_apply_kernel: the seven per-channel coefficient vectors are loaded
-// once per thread, two data vectors are in flight per trip)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
@@ -391,70 +370,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C,
     const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
   constexpr int N = V16<T>::N;
-  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-  const int c0 = (int)((i0 * N) % C);
-  float mu[N], is[N], k0[N], k1[N], k2[N], msc[N], msf[N];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float g[N], yy[N], o[N];
+    V16<T>::load(dA + i * N, g);
+    V16<T>::load(y + i * N, yy);
+    if (mask_scale != nullptr) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int c = c0 + k;
-    mu[k] = mean[c];
-    is[k] = invstd[c];
-    k0[k] = coef[c];
-    k1[k] = coef[C + c];
-    k2[k] = coef[2 * C + c];
-    msc[k] = mask_scale != nullptr ? mask_scale[c] : 0.f;
-    msf[k] = mask_scale != nullptr ? mask_shift[c] : 0.f;
-  }
-  const bool from_y = mask_scale != nullptr, from_a = !from_y && a != nullptr;
-  const bool racc = dres != nullptr && dres_acc;
-  auto finish = [&](long i, float (&g)[N], const float (&yy)[N], const float (&aa)[N], const float (&d)[N]) {
-    float o[N];
-    if (from_y) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
-    } else if (from_a) {
+      for (int k = 0; k < N; ++k) g[k] = (yy[k] * mask_scale[c0 + k] + mask_shift[c0 + k]) > 0.f ? g[k] : 0.f;
+    } else if (a != nullptr) {
+      float aa[N];
+      V16<T>::load(a + i * N, aa);
 #pragma unroll
       for (int k = 0; k < N; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float xhat = (yy[k] - mu[k]) * is[k];
-      o[k] = k0[k] * (g[k] - k1[k] - xhat * k2[k]);
+      const int c = c0 + k;
+      const float xhat = (yy[k] - mean[c]) * invstd[c];
+      o[k] = coef[c] * (g[k] - coef[C + c] - xhat * coef[2 * C + c]);
     }
     V16<T>::store(dy + i * N, o);
     if (dres != nullptr) {
-      if (racc) {
+      if (dres_acc) {
+        float d[N];
+        V16<T>::load(dres + i * N, d);
 #pragma unroll
         for (int k = 0; k < N; ++k) g[k] += d[k];
       }
       V16<T>::store(dres + i * N, g);
     }
-  };
-  long i = i0;
-  for (; i + stride < nvec; i += 2 * stride) {
-    float g0[N], g1[N], y0[N], y1[N], a0[N] = {}, a1[N] = {}, d0[N] = {}, d1[N] = {};
-    V16<T>::load(dA + i * N, g0);
-    V16<T>::load(dA + (i + stride) * N, g1);
-    V16<T>::load(y + i * N, y0);
-    V16<T>::load(y + (i + stride) * N, y1);
-    if (from_a) {
-      V16<T>::load(a + i * N, a0);
-      V16<T>::load(a + (i + stride) * N, a1);
-    }
-    if (racc) {
-      V16<T>::load(dres + i * N, d0);
-      V16<T>::load(dres + (i + stride) * N, d1);
-    }
-    finish(i, g0, y0, a0, d0);
-    finish(i + stride, g1, y1, a1, d1);
-  }
-  if (i < nvec) {
-    float g0[N], y0[N], a0[N] = {}, d0[N] = {};
-    V16<T>::load(dA + i * N, g0);
-    V16<T>::load(y + i * N, y0);
-    if (from_a) V16<T>::load(a + i * N, a0);
-    if (racc) V16<T>::load(dres + i * N, d0);
-    finish(i, g0, y0, a0, d0);
   }
 }
 
