@@ -83,6 +83,11 @@ static Geo geo(int dtype, const d3f_conv_desc* d) {
   return g;
 }
 
+static bool desc_upfold(int dtype, const d3f_conv_desc* d) {
+  static const bool off = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob (same as the engine's)
+  return !off && upfold_applies(sdt(dtype), d->upsample0, d->KH, d->stride, d->pad, d->C0, d->C1);
+}
+
 static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk = false) {
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
@@ -94,7 +99,42 @@ static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool all
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.M = d->B * g.Ho * g.Wo;
   p.mode = CONV_RAW_STATS;
+  if (desc_upfold(dtype, d)) {  // up-sampling folded into pre-summed weights: rows = one output-parity class
+    p.par = 3;
+    p.shift0 = 0;
+    p.Ho = p.H0s; p.Wo = p.W0s;
+    p.M = d->B * p.H0s * p.W0s;
+    p.Kpad = 4 * d->C0 + 9 * d->C1;
+  }
   return conv_igemm_plan(p, dtype, allow_splitk);
+}
+
+// data gradient of an up-sample-folded layer: (lo) 4x4 stride-2 convolution over dY -> gradient of the LOW-resolution
+// source [B][H/2][W/2][C0]; (skip) ordinary 3x3 data gradient -> gradient of the skip tensor [B][H][W][C1]
+static int upfold_dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& lo, ConvParams& sk, bool allow_splitk) {
+  const Geo g = geo(dtype, d);
+  std::memset(&lo, 0, sizeof(lo));
+  std::memset(&sk, 0, sizeof(sk));
+  lo.B = d->B; lo.C0 = g.CoutD; lo.C1 = 0;
+  lo.Hv = lo.H0s = d->H; lo.Wv = lo.W0s = d->W;
+  lo.Ho = d->H / 2; lo.Wo = d->W / 2;
+  lo.Cout = d->C0; lo.CoutPad = (int)round_up(d->C0, 16); lo.Kpad = 16 * g.CoutD;
+  lo.KH = lo.KW = 4; lo.stride = 2; lo.pad = 1;
+  lo.M = d->B * lo.Ho * lo.Wo;
+  lo.mode = CONV_DGRAD;
+  lo.out_c0 = d->C0;
+  if (int rc = conv_igemm_plan(lo, dtype, allow_splitk)) return rc;
+  if (d->C1 > 0) {
+    sk.B = d->B; sk.C0 = g.CoutD; sk.C1 = 0;
+    sk.Hv = sk.H0s = sk.Ho = d->H; sk.Wv = sk.W0s = sk.Wo = d->W;
+    sk.Cout = d->C1; sk.CoutPad = (int)round_up(d->C1, 16); sk.Kpad = g.KpadD;
+    sk.KH = sk.KW = 3; sk.stride = 1; sk.pad = 1;
+    sk.M = d->B * d->H * d->W;
+    sk.mode = CONV_DGRAD;
+    sk.out_c0 = d->C1;
+    if (int rc = conv_igemm_plan(sk, dtype, allow_splitk)) return rc;
+  }
+  return 0;
 }
 
 static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk) {
@@ -256,19 +296,41 @@ size_t d3f_conv_packed_bytes(int dtype, const d3f_conv_desc* d, int which) {
   if (desc_check(dtype, d) != 0) return 0;
   const Geo g = geo(dtype, d);
   const size_t es = dtype == D3F_F32X3 ? 6 : (dtype == D3F_F32 ? 4 : 2);  // x3: three bf16 planes
+  if (desc_upfold(dtype, d)) {
+    // forward: four per-class matrices; data gradient: [wd4 (low-resolution source) | wds (skip tensor)]
+    const size_t c0r = (size_t)round_up(d->C0, 16), c1r = (size_t)round_up(d->C1, 16);
+    return which == 0 ? (size_t)4 * g.CoutPad * (4 * d->C0 + 9 * d->C1) * es
+                      : (c0r * 16 * g.CoutD + c1r * g.KpadD) * es;
+  }
   return which == 0 ? (size_t)g.CoutPad * g.Kpad * es : (size_t)g.CinRows * g.KpadD * es;
 }
 int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
                           void* stream) {
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
+  if (desc_upfold(dtype, d)) {
+    const size_t es = dtype == D3F_F32X3 ? 6 : (dtype == D3F_F32 ? 4 : 2);
+    const int c0r = (int)round_up(d->C0, 16), c1r = (int)round_up(d->C1, 16);
+    D3F_CHECK(w_fwd != nullptr && d->CinReal == d->C0 + d->C1, "conv_pack_weights: up-sample folded layer");
+    char* wds = w_dgrad ? reinterpret_cast<char*>(w_dgrad) + (size_t)c0r * 16 * g.CoutD * es : nullptr;
+    return pack_up_launch(dtype, w, d->Cout, d->C0, d->C1, w_fwd, g.CoutPad, w_dgrad, c0r,
+                          d->C1 > 0 ? wds : nullptr, c1r, (hipStream_t)stream);
+  }
   return pack_weights_launch(dtype, w, d->Cout, d->CinReal, g.Cin, d->KH, d->KW, w_fwd, g.CoutPad, g.Kpad,
                              w_dgrad, g.CinRows, g.KpadD,
                              parity_dgrad_applies(dtype, d->stride, d->KH, d->pad, g.CoutD, d->C1) ? 2 : 1,
                              (hipStream_t)stream);
 }
+int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d) {
+  return (d != nullptr && desc_check(dtype, d) == 0 && desc_upfold(dtype, d)) ? 1 : 0;
+}
 size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
   ConvParams p;
+  if (which != 0 && desc_check(dtype, d) == 0 && desc_upfold(dtype, d)) {
+    ConvParams lo, sk;
+    if (upfold_dgrad_params(dtype, d, lo, sk, true) != 0) return 0;
+    return std::max(conv_splitk_floats(lo), d->C1 > 0 ? conv_splitk_floats(sk) : (size_t)0) * sizeof(float);
+  }
   const int rc = which == 0 ? fwd_params(dtype, d, p, true) : dgrad_params(dtype, d, p, true);
   return rc != 0 ? 0 : conv_splitk_floats(p) * sizeof(float);
 }
@@ -291,6 +353,26 @@ int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const 
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
                            void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream) {
   ConvParams p;
+  if (desc_check(dtype, d) == 0 && desc_upfold(dtype, d)) {
+    // dx0 = gradient of the LOW-resolution source [B][H/2][W/2][C0], dx1 = gradient of the skip tensor
+    ConvParams lo, sk;
+    if (int rc = upfold_dgrad_params(dtype, d, lo, sk, workspace != nullptr)) return rc;
+    if (d->B == 0) return 0;
+    D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
+    const Geo g = geo(dtype, d);
+    const size_t es = dtype == D3F_F32X3 ? 6 : (dtype == D3F_F32 ? 4 : 2);
+    lo.src0 = dy; lo.w = w_dgrad; lo.out0 = dx0; lo.acc0 = acc0;
+    lo.partial = lo.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+    if (int rc = conv_igemm_launch(lo, dtype, (hipStream_t)stream)) return rc;
+    if (d->C1 > 0) {
+      sk.src0 = dy;
+      sk.w = reinterpret_cast<const char*>(w_dgrad) + (size_t)round_up(d->C0, 16) * 16 * g.CoutD * es;
+      sk.out0 = dx1; sk.acc0 = acc1;
+      sk.partial = sk.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+      if (int rc = conv_igemm_launch(sk, dtype, (hipStream_t)stream)) return rc;
+    }
+    return 0;
+  }
   if (int rc = dgrad_params(dtype, d, p, workspace != nullptr)) return rc;
   if (d && d->B == 0) return 0;
   D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");

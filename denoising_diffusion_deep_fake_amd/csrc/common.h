@@ -116,7 +116,10 @@ struct ConvParams {
   int Ho, Wo, Cout;    // output extent, real output channels
   int CoutPad, Kpad;
   int w_ld;            // elements between packed weight rows (= Kpad; filled by plan)
-  int par;             // CONV_DGRAD of a stride-2 conv by output-parity classes: 1 = 3x3 pad 1, 2 = 1x1 pad 0 (0: off)
+  int par;             // output-parity classes.  CONV_DGRAD of a stride-2 conv: 1 = 3x3 pad 1, 2 = 1x1 pad 0;
+                       // forward of conv(cat(upsample2x(src0), src1)) with the up-sampling folded into pre-summed
+                       // weights: 3 (src0 is then described at its own low resolution H0s x W0s, shift0 = 0)
+  int nz;              // classes in the launch (grid.z), filled by plan: 4 for par 1 / 3, else 1
   int KH, KW, stride, pad;
   int M;               // B*Ho*Wo
   int tiles_m, tiles_n;
@@ -136,11 +139,18 @@ struct ConvParams {
   const void* bn_y;
   const float* bn_coef;
   float* bn_partial;
+  const void* bn_a;    // that layer's activation when its ReLU mask cannot be recomputed from y (residual add) or null
 };
 
 struct ConvTile {
   int BM, BN;
 };
+// Does conv(cat(upsample2x(x0), x1)) run with the up-sampling folded into pre-summed weights (ConvParams::par == 3
+// forward, 4x4 stride-2 data gradient)?  Needs whole k-tiles per tap in both sources.
+static inline bool upfold_applies(int dtype, int upsample0, int k, int stride, int pad, int C0, int C1) {
+  const int bke = dtype == D3F_BF16 ? 64 : 32;
+  return upsample0 && k == 3 && stride == 1 && pad == 1 && C0 > 0 && (C0 % bke) == 0 && (C1 % bke) == 0;
+}
 // Does the data gradient of this convolution run as the parity-class decomposition (ConvParams::par)?  The weight
 // packers (pointwise.hip) store the flipped taps class by class exactly when it does, so both ask this one function.
 static inline bool parity_dgrad_applies(int dtype, int stride, int k, int pad, int CoutD, int C1) {

@@ -198,11 +198,37 @@ extern "C" int d3f_debug_phase_read(unsigned long long out[8], int reset) {
 constexpr int LDS_ROW = 36;  // dwords per LDS row: 128 B of data + 16 B pad
 constexpr int X3_ROW = 16;   // x3 mode: dwords per LDS row of one bf16 plane (32 bf16, XOR-swizzled, no pad)
 
+// Output-parity classes (ConvParams::par): row m = (b, j, i) of class (py, px) is pixel (2j+py, 2i+px) of the
+// [B][2*Ho][2*Wo] output.  par 1: blockIdx.z = (1,1) (1,0) (0,1) (0,0) (longest k-range first); par 3: z = 2*py + px.
+__device__ __forceinline__ void par_class(int par, int z, int& py, int& px) {
+  if (par == 1) {
+    py = z < 2 ? 1 : 0;
+    px = (z == 0 || z == 2) ? 1 : 0;
+  } else if (par == 3) {
+    py = z >> 1;
+    px = z & 1;
+  } else {
+    py = px = 0;
+  }
+}
+__device__ __forceinline__ long par_out_row(const ConvParams& p, int py, int px, int m) {
+  const int HoWo = p.Ho * p.Wo;
+  const int b = m / HoWo, r = m - b * HoWo;
+  const int j = r / p.Wo, i = r - j * p.Wo;
+  return ((long)b * (2 * p.Ho) + 2 * j + py) * (2 * p.Wo) + 2 * i + px;
+}
+
 // SMALLC: Cin < one k-row (taps decoded per lane).  FAST: plain gather (one source, no up-sampling /
 // zero insertion, <= 32 taps): per-row base offset + tap-validity bitmask are computed once, so a
 // k-tile costs ~4 VALU per gathered vector.  This matters because the f32 MFMA runs at the f32 VALU
 // rate and VALU time ADDS to it (microbenchmark in profiles/README.md): VALU per MFMA is the lever.
-template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, bool FAST, bool X3>
+//
+// FAST == 2: the decoder's conv(cat(upsample2x(x0), x1)) by output-parity classes with the up-sampling folded into
+// pre-summed weights (pointwise.hip, pack_up_kernel): blockIdx.z = class (py, px), rows = the class's output pixels
+// (2j+py, 2i+px), and the k-loop runs two plain gathers back to back -- segment A: 2x2 taps on the LOW-resolution
+// x0 at (j + py - 1 + a, i + px - 1 + b), segment B: the usual 3x3 taps on the skip tensor x1 -- 4*C0 + 9*C1
+// multiply-adds per output instead of 9*(C0 + C1).
+template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, int FAST, bool X3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int VE = Elem<T>::VE, BKE = Elem<T>::BKE;
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / MT, FN = TN / MT;
@@ -246,10 +272,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // the packed weight rows hold the taps class by class (pointwise.hip: dgrad_tap_slot), so a class is a k-offset.
   int KH_ = p.KH, KW_ = p.KW, Kc = p.Kpad, par_py = 0, par_px = 0;
   unsigned wk0 = 0;  // first weight element (k index) of this launch slice
+  par_class(p.par, (int)blockIdx.z, par_py, par_px);
   if (p.par == 1) {       // 3x3, pad 1
     const int z = blockIdx.z;
-    par_py = z < 2 ? 1 : 0;
-    par_px = (z == 0 || z == 2) ? 1 : 0;
     KH_ = 1 + par_py;
     KW_ = 1 + par_px;
     Kc = KH_ * KW_ * p.C0;
@@ -257,7 +282,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   } else if (p.par == 2) {  // 1x1, pad 0: only even pixels receive anything (the launch covers class (0,0) alone)
     KH_ = KW_ = 1;
     Kc = p.C0;
-  }
+  }  // par 3 (up-sample folded forward): every class has its own weight matrix [CoutPad][Kpad]
+  // two-segment gather (FAST == 2): k-tiles [0, nkA) come from segment A, the rest from segment B
+  const int cptA = p.C0 / BKE, cptB = p.C1 / BKE;
+  const int nkA = FAST == 2 ? 4 * cptA : 0;
 
   // ---- per-row output pixel -> input origin -----------------------------------------
   int iy0[NVA], ix0[NVA], bidx[NVA];
@@ -284,7 +312,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   // FAST mode: byte offset of (row, tap 0, this lane's chunk) and a bit per tap "inside the image"
   unsigned rowoff[NVA], vmask[NVA];
-  if (FAST) {
+  constexpr int NVA2 = FAST == 2 ? NVA : 1;
+  unsigned rowoffB[NVA2], vmaskB[NVA2];  // FAST == 2: the same for segment B (3x3 on the skip tensor)
+  if constexpr (FAST == 2) {
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool rowok = m < p.M;
+      const int b = m / HoWo, r = m - b * HoWo;
+      const int j = r / p.Wo, ii = r - j * p.Wo;
+      const int ya = j + par_py - 1, xa = ii + par_px - 1;          // low-resolution origin (tap a = b = 0)
+      const int yb = 2 * j + par_py - 1, xb = 2 * ii + par_px - 1;  // full-resolution origin of the skip taps
+      rowoff[i] = (unsigned)(((b * p.H0s + ya) * p.W0s + xa) * p.C0 + chunk * VE) * (unsigned)sizeof(T);
+      rowoffB[i] = (unsigned)(((b * p.Hv + yb) * p.Wv + xb) * p.C1 + chunk * VE) * (unsigned)sizeof(T);
+      unsigned mk = 0, mkb = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int iy = ya + (t >> 1), ix = xa + (t & 1);
+        mk |= (unsigned)(rowok & ((unsigned)iy < (unsigned)p.H0s) & ((unsigned)ix < (unsigned)p.W0s)) << t;
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = yb + t / 3, ix = xb + t % 3;
+        mkb |= (unsigned)(rowok & ((unsigned)iy < (unsigned)p.Hv) & ((unsigned)ix < (unsigned)p.Wv)) << t;
+      }
+      vmask[i] = mk;
+      vmaskB[i] = mkb;
+    }
+  } else if (FAST) {
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const bool rowok = iy0[i] > -(1 << 23);
@@ -313,8 +369,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int kt_begin = (int)((long)nk_total * blockIdx.y / p.splitk);
   const int kt_end = (int)((long)nk_total * (blockIdx.y + 1) / p.splitk);
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
-  int t_kh = 0, t_kw = 0, t_c = 0;
-  if (!SMALLC && kt_begin > 0) {
+  int t_kh = 0, t_kw = 0, t_c = 0, t_seg = 0;
+  if (FAST == 2) {
+    if (kt_begin < nkA) {
+      const int tap = kt_begin / cptA;
+      t_c = (kt_begin - tap * cptA) * BKE;
+      t_kh = tap >> 1;
+      t_kw = tap & 1;
+    } else {
+      const int kb = kt_begin - nkA, tap = cptB > 0 ? kb / cptB : 0;
+      t_c = (kb - tap * cptB) * BKE;
+      t_kh = tap / 3;
+      t_kw = tap - t_kh * 3;
+      t_seg = 1;
+    }
+  } else if (!SMALLC && kt_begin > 0) {
     const int cpos = kt_begin * BKE;
     const int tap = cpos / Cin;
     t_c = cpos - tap * Cin;
@@ -329,7 +398,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t r1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
   const int w_row_bytes = X3 ? p.w_ld * 2 : p.w_ld * (int)sizeof(T);
-  const unsigned wk0_bytes = wk0 * (X3 ? 2u : (unsigned)sizeof(T));
+  // par 3: class z owns the matrix (x3: the three planes) at z * [planes] * CoutPad rows
+  const unsigned wk0_bytes = wk0 * (X3 ? 2u : (unsigned)sizeof(T)) +
+                             (p.par == 3 ? (unsigned)blockIdx.z * (unsigned)((X3 ? 3 : 1) * p.CoutPad * w_row_bytes) : 0u);
   unsigned woff[NVB];
   int x3_bdst[NVB];  // x3: LDS dword offset of this thread's weight pieces inside the B planes (-1: no piece)
 #pragma unroll
@@ -360,12 +431,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int tapvalid, parity_mask, Cs, sh, Hs, Ws;
     unsigned tapdelta, tapbit;  // FAST mode (wave-uniform)
     bool from0;
+    int seg;                    // FAST == 2: segment of this k-tile
   };
   auto tile_setup = [&](int kt) {
     TileCtx x;
     x.kt = kt;
     x.tapvalid = 1;
     x.from0 = true;
+    x.seg = 0;
+    if constexpr (FAST == 2) {
+      // segment A: 2x2 taps, rows of W0s pixels x C0 channels; segment B: 3x3 taps, rows of Wv pixels x C1 channels
+      x.seg = t_seg;
+      const int wp = t_seg ? p.Wv : p.W0s, cs = t_seg ? p.C1 : p.C0, kws = t_seg ? 3 : 2;
+      x.kh = t_kh;
+      x.kw = t_kw;
+      x.c = t_c + chunk * VE;
+      x.tapdelta = (unsigned)((t_kh * wp + t_kw) * cs + t_c) * (unsigned)sizeof(T);
+      x.tapbit = (unsigned)(t_kh * kws + t_kw);
+      t_c += BKE;
+      const int wrap_c = t_c >= cs ? 1 : 0;
+      t_c = wrap_c ? 0 : t_c;
+      t_kw += wrap_c;
+      const int wrap_w = t_kw == kws ? 1 : 0;
+      t_kw = wrap_w ? 0 : t_kw;
+      t_kh += wrap_w;
+      const int sw = (t_seg == 0 && t_kh == 2) ? 1 : 0;  // segment A done
+      t_kh = sw ? 0 : t_kh;
+      t_seg |= sw;
+    } else
     if (SMALLC) {
       // per-lane tap decode without integer divisions (two of them cost ~80 VALU per k-tile): the small-channel
       // layers have power-of-two Cin, and tap / KW is a multiply-shift (exact for tap < 2^16 / KW)
@@ -403,7 +496,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // divergent branch and split the loop body into many basic blocks.
   auto tile_piece = [&](const TileCtx& x, auto qc) {
     constexpr int q = decltype(qc)::value;
-    if constexpr (q < NVA && FAST) {
+    if constexpr (q < NVA && FAST == 2) {
+      const unsigned o = (x.seg ? rowoffB[q] : rowoff[q]) + x.tapdelta;
+      const unsigned vm = x.seg ? vmaskB[q] : vmask[q];
+      ra[q] = buf_load16(x.seg ? r1 : r0, ((vm >> x.tapbit) & 1u) ? o : BUF_OOB);
+    } else if constexpr (q < NVA && FAST) {
       const unsigned o = rowoff[q] + x.tapdelta;
       ra[q] = buf_load16(r0, ((vmask[q] >> x.tapbit) & 1u) ? o : BUF_OOB);
     } else if constexpr (q < NVA) {
@@ -551,23 +648,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // with one NHWC source the byte offset of a k-tile advances by 128 per tile and jumps once per filter
     // row -- and two register sets keep the loads of tiles t+2 and t+3 in flight while tile t computes.
     const unsigned step_bytes = BKE * (unsigned)sizeof(T);  // activations; weights advance by WSTEP
-    const int cpt = Cin / BKE;                                        // k-tiles per tap
-    const unsigned rowjump = (unsigned)((p.Wv - KW_) * p.C0) * (unsigned)sizeof(T);
+    // per segment (FAST == 2: A = 2x2 on x0 [W0s pixels x C0], B = 3x3 on x1 [Wv pixels x C1]; else one segment)
+    int cpt = FAST == 2 ? cptA : Cin / BKE;                           // k-tiles per tap
+    int kw_cur = FAST == 2 ? 2 : KW_;
+    unsigned rowjump = FAST == 2 ? (unsigned)((p.W0s - 2) * p.C0) * (unsigned)sizeof(T)
+                                 : (unsigned)((p.Wv - KW_) * p.C0) * (unsigned)sizeof(T);
+    const unsigned rowjumpB = (unsigned)((p.Wv - 3) * p.C1) * (unsigned)sizeof(T);
     unsigned ld_delta, ld_bit, ld_w;                                  // state of the LOAD stream (runs ahead)
     int ld_cleft, ld_kwleft;
-    {
+    int ld_seg = 0, ld_segleft = 0x7fffffff;                          // FAST == 2: segment, k-tiles left in it
+    if (FAST == 2 && kt_begin >= nkA) {
+      const int kb = kt_begin - nkA, tap0 = cptB > 0 ? kb / cptB : 0, c0 = kb - tap0 * cptB;
+      const int kh0 = tap0 / 3, kw0 = tap0 - kh0 * 3;
+      ld_seg = 1;
+      cpt = cptB;
+      kw_cur = 3;
+      rowjump = rowjumpB;
+      ld_delta = (unsigned)((kh0 * p.Wv + kw0) * p.C1 + c0 * BKE) * (unsigned)sizeof(T);
+      ld_bit = (unsigned)tap0;
+      ld_cleft = cptB - c0;
+      ld_kwleft = 3 - kw0;
+    } else {
+      const int wp = FAST == 2 ? p.W0s : p.Wv;
       const int tap0 = kt_begin / cpt, c0 = kt_begin - tap0 * cpt;
-      const int kh0 = tap0 / KW_, kw0 = tap0 - kh0 * KW_;
-      ld_delta = (unsigned)((kh0 * p.Wv + kw0) * p.C0 + c0 * BKE) * (unsigned)sizeof(T);
+      const int kh0 = tap0 / kw_cur, kw0 = tap0 - kh0 * kw_cur;
+      ld_delta = (unsigned)((kh0 * wp + kw0) * p.C0 + c0 * BKE) * (unsigned)sizeof(T);
       ld_bit = (unsigned)tap0;
       ld_cleft = cpt - c0;
-      ld_kwleft = KW_ - kw0;
-      ld_w = (unsigned)kt_begin * WSTEP;
+      ld_kwleft = kw_cur - kw0;
+      if (FAST == 2) ld_segleft = nkA - kt_begin;
     }
+    ld_w = (unsigned)kt_begin * WSTEP;
     uint4 ra2[NVA], rb2[NVB];  // second register set
     auto issue_piece = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB], auto qc) {
       constexpr int q = decltype(qc)::value;
-      if constexpr (q < NVA) {
+      if constexpr (q < NVA && FAST == 2) {
+        const unsigned vm = ld_seg ? vmaskB[q] : vmask[q], ro = ld_seg ? rowoffB[q] : rowoff[q];
+        A[q] = buf_load16(ld_seg ? r1 : r0, ((vm >> ld_bit) & 1u) ? ro + ld_delta : BUF_OOB);
+      } else if constexpr (q < NVA) {
         A[q] = buf_load16(r0, ((vmask[q] >> ld_bit) & 1u) ? rowoff[q] + ld_delta : BUF_OOB);
       } else {
         Bv[q - NVA] = buf_load16(rw, woff[q - NVA] + ld_w);  // an OOB row keeps bit 31 set
@@ -581,8 +699,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ld_bit += (unsigned)tapwrap;
       ld_kwleft -= tapwrap;
       const int rowwrap = (ld_kwleft == 0) ? 1 : 0;
-      ld_kwleft = rowwrap ? KW_ : ld_kwleft;
+      ld_kwleft = rowwrap ? kw_cur : ld_kwleft;
       ld_delta += rowwrap ? rowjump : 0u;
+      if constexpr (FAST == 2) {  // end of segment A: restart the tap walk on the skip tensor
+        const int sw = (--ld_segleft == 0) ? 1 : 0;
+        ld_seg |= sw;
+        cpt = sw ? cptB : cpt;
+        kw_cur = sw ? 3 : kw_cur;
+        rowjump = sw ? rowjumpB : rowjump;
+        ld_delta = sw ? 0u : ld_delta;
+        ld_bit = sw ? 0u : ld_bit;
+        ld_cleft = sw ? cptB : ld_cleft;
+        ld_kwleft = sw ? 3 : ld_kwleft;
+      }
     };
     auto issue_all = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
       [&]<int... Q>(std::integer_sequence<int, Q...>) {
@@ -761,7 +890,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const bool n_ok = n < p.Cout;              // Cout is a multiple of 4 on every vector path (plan)
 
   if (p.splitk > 1) {
-    float* __restrict__ slab = p.partial + (long)blockIdx.y * p.M * p.Cout;
+    // slab rows: class-major virtual rows z * M + m (the reduce kernel maps them to output pixels)
+    float* __restrict__ slab = p.partial + ((long)blockIdx.y * p.nz + blockIdx.z) * p.M * p.Cout;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int row = rv0 + i * RSTEP, m = m0 + row;
@@ -796,7 +926,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int row = rv0 + i * RSTEP, m = m0 + row;
-      if (n_ok && m < p.M) store4(out + (long)m * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
+      if (n_ok && m < p.M) {
+        const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
+        store4(out + orow * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
+      }
     }
     if (p.stats != nullptr) {
       // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
@@ -822,8 +955,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
         const int nn = n0 + tid;
         if (nn < p.CoutPad) {
-          p.stats[((long)tile_m * p.CoutPad + nn) * 2 + 0] = a1;
-          p.stats[((long)tile_m * p.CoutPad + nn) * 2 + 1] = a2;
+          const long st = (long)blockIdx.z * p.tiles_m + tile_m;  // one partial row per (class, m-tile)
+          p.stats[(st * p.CoutPad + nn) * 2 + 0] = a1;
+          p.stats[(st * p.CoutPad + nn) * 2 + 1] = a2;
         }
       }
     }
@@ -838,12 +972,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
         v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+        const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
         if (res != nullptr) {
-          const float4 rr = load4(res + (long)m * p.Cout + n);
+          const float4 rr = load4(res + orow * p.Cout + n);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        store4(out + (long)m * p.Cout + n, v);
+        store4(out + orow * p.Cout + n, v);
       }
     }
   } else if (p.mode == CONV_DGRAD) {
@@ -859,25 +994,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int row = rv0 + i * RSTEP, m = m0 + row;
         if (m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
-        long orow = m;
-        if (p.par) {  // row m = (b, jy, jx) of this parity class -> input pixel (2jy+py, 2jx+px)
-          const int HoWo = p.Ho * p.Wo;
-          const int b = m / HoWo, r = m - b * HoWo;
-          const int jy = r / p.Wo, jx = r - jy * p.Wo;
-          orow = ((long)b * (2 * p.Ho) + 2 * jy + par_py) * (2 * p.Wo) + 2 * jx + par_px;
-        }
+        const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
         T* dst = base + orow * ld;
         if (accum) {
           const float4 o = load4(dst);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          // a fused BatchNorm reduction (below) works on the FINAL gradient: this launch is its last writer
+          if (p.bn_partial != nullptr) *reinterpret_cast<float4*>(&Cs[row * LDC + cv * 4]) = v;
         }
         store4(dst, v);
       }
     }
     if (p.bn_partial != nullptr) {
-      // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, no accumulate):
-      // column sums over this tile's rows of dz and dz * xhat, with the ReLU mask recomputed from y by the
-      // forward's own arithmetic
+      // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, this launch is the last
+      // writer of the gradient): column sums over this tile's rows of dz and dz * xhat.  ReLU mask: recomputed from
+      // y by the forward's own arithmetic, or -- layers with a residual, bn_a != null -- read from the activation
+      if (p.acc0) __syncthreads();  // the accumulated values above were written back to the C tile
       constexpr int NG = 256 / BN;
       const int col = tid % BN, rg = tid / BN;
       const int nn = n0 + col, C = p.Cout;
@@ -885,12 +1017,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const float mu = cok ? p.bn_coef[nn] : 0.f, is = cok ? p.bn_coef[C + nn] : 0.f;
       const float sc = cok ? p.bn_coef[2 * C + nn] : 0.f, sf = cok ? p.bn_coef[3 * C + nn] : 0.f;
       const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+      const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
       float s1 = 0.f, s2 = 0.f;
       for (int row = rg; row < BM; row += NG) {
         const int m = m0 + row;
         if (cok && m < p.M) {
           const float yy = to_f32<T>(yb[(long)m * C + nn]);
-          const float g = (yy * sc + sf) > 0.f ? Cs[row * LDC + col] : 0.f;
+          const float keep = ab != nullptr ? to_f32<T>(ab[(long)m * C + nn]) : yy * sc + sf;
+          const float g = keep > 0.f ? Cs[row * LDC + col] : 0.f;
           s1 += g;
           s2 += g * ((yy - mu) * is);
         }
@@ -931,14 +1065,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
   const int VC = p.Cout / 4;   // 16-byte vectors per row; 256 % VC == 0 (plan)
   const int RP = 256 / VC;     // rows per pass
   const int cv = threadIdx.x % VC, r0 = threadIdx.x / VC;
+  // rows are class-major virtual rows mv = z * M + m (one class unless ConvParams::par splits the output)
+  const int MV = p.nz * p.M;
   const int m_begin = blockIdx.x * SK_ROWS;
-  const int m_end = min(m_begin + SK_ROWS, p.M);
-  const long MN = (long)p.M * p.Cout;
+  const int m_end = min(m_begin + SK_ROWS, MV);
+  const long MN = (long)MV * p.Cout;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
   T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
-  for (int m = m_begin + r0; m < m_end; m += RP) {
-    const long e = (long)m * p.Cout + cv * 4;
+  for (int mv = m_begin + r0; mv < m_end; mv += RP) {
+    const long e = (long)mv * p.Cout + cv * 4;  // position in a slab
+    long m = mv;                                // output row
+    if (p.par) {
+      const int z = mv / p.M;
+      int py, px;
+      par_class(p.par, z, py, px);
+      m = par_out_row(p, py, px, mv - z * p.M);
+    }
+    const long eo = m * p.Cout + cv * 4;        // position in the output tensor
     // all slabs in flight at once (splitk is wave-uniform: scalar branches), summed in slab order
     float4 w[SK_MAX];
 #pragma unroll
@@ -954,7 +1098,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
       for (int k = 0; k < 4; ++k) {
         s1[k] += vv[k];
         s2[k] += vv[k] * vv[k];
-        o0[e + k] = from_f32<T>(vv[k]);
+        o0[eo + k] = from_f32<T>(vv[k]);
       }
     } else if (p.mode == CONV_EVAL_FUSED) {  // folded BatchNorm (+ residual) (+ ReLU), as the fused epilogue
       const int n = cv * 4;
@@ -962,9 +1106,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float x = vv[k] * p.scale[n + k] + p.shift[n + k];
-        if (res != nullptr) x += to_f32<T>(res[e + k]);
+        if (res != nullptr) x += to_f32<T>(res[eo + k]);
         if (p.relu) x = fmaxf(x, 0.f);
-        o0[e + k] = from_f32<T>(x);
+        o0[eo + k] = from_f32<T>(x);
       }
     } else {  // CONV_DGRAD
       const int n = cv * 4;
@@ -976,14 +1120,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
         float x = vv[k];
         if (accum) x += to_f32<T>(dst[k]);
         dst[k] = from_f32<T>(x);
+        vv[k] = x;  // the fused reduction below works on the final gradient
       }
       if (p.bn_partial != nullptr) {  // fused BatchNorm-backward reduction of the consuming layer (see the kernel)
         const int C = p.Cout;
         const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+        const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float yy = to_f32<T>(yb[e + k]);
-          const float g = (yy * p.bn_coef[2 * C + n + k] + p.bn_coef[3 * C + n + k]) > 0.f ? vv[k] : 0.f;
+          const float yy = to_f32<T>(yb[eo + k]);
+          const float keep = ab != nullptr ? to_f32<T>(ab[eo + k]) : yy * p.bn_coef[2 * C + n + k] + p.bn_coef[3 * C + n + k];
+          const float g = keep > 0.f ? vv[k] : 0.f;
           s1[k] += g;
           s2[k] += g * ((yy - p.bn_coef[n + k]) * p.bn_coef[C + n + k]);
         }
@@ -1038,14 +1185,15 @@ static ConvTile pick_tile(const ConvParams& p, bool x3) {
   if (co <= 32) return {256, 32};
   // prefer the biggest tile that still gives >= 2 blocks per CU; small problems fall to 64x64
   const long M = p.M;
-  auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn); };
+  const int nz = (p.par == 1 || p.par == 3) ? 4 : 1;  // output-parity classes share the launch
+  auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn) * nz; };
   if (co % 128 == 0 && blocks(128, 128) >= 512) return {128, 128};
   if (blocks(128, 64) >= 512) return {128, 64};
   return {64, 64};
 }
 
 size_t conv_splitk_floats(const ConvParams& p) {
-  return p.splitk > 1 ? (size_t)p.splitk * p.M * p.Cout : 0;
+  return p.splitk > 1 ? (size_t)p.splitk * (p.nz > 0 ? p.nz : 1) * p.M * p.Cout : 0;
 }
 
 int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
@@ -1056,7 +1204,16 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
             p.C0, p.C1, ve);
   D3F_CHECK(p.Kpad % bke == 0 && (p.par || p.Kpad >= p.KH * p.KW * (p.C0 + p.C1)),
             "conv: Kpad %d inconsistent with K=%d", p.Kpad, p.KH * p.KW * (p.C0 + p.C1));
-  if (p.par) {
+  p.nz = (p.par == 1 || p.par == 3) ? 4 : 1;
+  if (p.par == 3) {
+    // up-sample folded forward (kernel comment, FAST == 2): src0 is the LOW-resolution tensor [B][H0s][W0s][C0],
+    // src1 the skip tensor [B][Hv][Wv][C1] with Hv = 2*H0s; rows = one parity class of the [B][Hv][Wv] output
+    D3F_CHECK((p.mode == CONV_RAW_STATS || p.mode == CONV_EVAL_FUSED) && p.shift0 == 0 && p.zi == 0 && p.KH == 3 &&
+                  p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Hv == 2 * p.H0s && p.Wv == 2 * p.W0s &&
+                  p.Ho == p.H0s && p.Wo == p.W0s && (p.C0 % bke) == 0 && (p.C1 % bke) == 0 && p.C0 > 0 &&
+                  p.Kpad == 4 * p.C0 + 9 * p.C1,
+              "conv: up-sample folded forward: unsupported description");
+  } else if (p.par) {
     // parity-decomposed stride-2 data gradient: four plain sub-convolutions over dY (kernel comment)
     D3F_CHECK(p.mode == CONV_DGRAD && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.stride == 1 && p.pad == 0 &&
                   p.Hv == p.Ho && p.Wv == p.Wo && !is_small_c(p, dtype) && p.out_c0 == p.Cout &&
@@ -1073,7 +1230,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   p.w_ld = p.Kpad;
   D3F_CHECK(p.shift0 == 0 || p.shift0 == 1, "conv: shift0");
   D3F_CHECK(!p.zi || p.shift0 == 1, "conv: zero insertion needs shift0");
-  D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "conv: src0 extent");
+  D3F_CHECK(p.par == 3 || (p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0)), "conv: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "conv: M");
   D3F_CHECK(p.CoutPad >= p.Cout, "conv: CoutPad");
   D3F_CHECK(p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0, "conv: Cout=%d must be a multiple of 4 (vector epilogue)", p.Cout);
@@ -1081,22 +1238,22 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(p.C1 == 0 || (p.C0 % bke) == 0, "conv: C0=%d must be a multiple of %d when a second source is concatenated", p.C0, bke);
   const long es = dtype == D3F_BF16 ? 2 : 4;
   const long b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es, b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
-  const long bw = dtype == D3F_F32X3 ? (long)p.CoutPad * p.Kpad * 6 : (long)p.CoutPad * p.Kpad * es;
+  const long bw = (p.par == 3 ? 4 : 1) * (dtype == D3F_F32X3 ? (long)p.CoutPad * p.Kpad * 6 : (long)p.CoutPad * p.Kpad * es);
   D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
   p.splitk = 1;
-  p.stat_rows = p.tiles_m;
+  p.stat_rows = p.nz * p.tiles_m;
   // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop
-  const long base = (long)p.tiles_m * p.tiles_n;
+  const long base = (long)p.tiles_m * p.tiles_n * p.nz;
   const int nk = p.Kpad / bke;
   const int vc = p.Cout / 4;
   static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob
   int f0, f1, f2;
   const bool forced = forced_tile(&f0, &f1, &f2);
-  if (allow_splitk && !p.par && !no_splitk && !is_small_c(p, dtype) && (base < 384 || forced) && (p.Cout % 4) == 0 && vc <= 256 &&
+  if (allow_splitk && (p.par == 0 || p.par == 3) && !no_splitk && !is_small_c(p, dtype) && (base < 384 || forced) && (p.Cout % 4) == 0 && vc <= 256 &&
       (256 % vc) == 0 && (p.mode == CONV_RAW_STATS || p.mode == CONV_DGRAD) &&
       (p.mode != CONV_DGRAD || (p.out_c0 % 4) == 0)) {
     int sk = (int)((640 + base - 1) / base);
@@ -1106,7 +1263,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
     if (forced_tile(&fbm, &fbn, &fsk)) sk = fsk > SK_MAX ? SK_MAX : fsk;
     if (sk > 1) {
       p.splitk = sk;
-      p.stat_rows = cdiv(p.M, SK_ROWS);
+      p.stat_rows = cdiv((long)p.nz * p.M, SK_ROWS);
     }
   }
   return 0;
@@ -1114,15 +1271,17 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool X3>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, p.par == 1 ? 4u : 1u), block(256);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, (unsigned)p.nz), block(256);
   static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
   const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
-  if (smallc)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true, false, X3>), grid, block, 0, stream, p);
+  if (p.par == 3)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, 2, X3>), grid, block, 0, stream, p);
+  else if (smallc)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, true, 0, X3>), grid, block, 0, stream, p);
   else if (fast)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, true, X3>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, 1, X3>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, false, X3>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, 0, X3>), grid, block, 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -1152,7 +1311,8 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
     if (ablate[0] == 'w' || ablate[0] == 'b') q.w_bytes = 0;                    // weights
   }
 #endif
-  D3F_CHECK(q.splitk == 1 || q.stat_rows == cdiv(q.M, SK_ROWS), "conv: split-K params were not planned");
+  D3F_CHECK(q.nz >= 1 && (q.splitk == 1 || q.stat_rows == cdiv((long)q.nz * q.M, SK_ROWS)),
+            "conv: split-K params were not planned");
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);
   if (prof) prof_begin(prof_cls, q.flops, stream);
@@ -1163,7 +1323,7 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   // average is the number rocprofv3's kernel trace reports for the same kernel
   if (prof) prof_end(stream);
   if (rc == 0 && q.splitk > 1) {
-    const dim3 grid((unsigned)cdiv(q.M, SK_ROWS)), block(256);
+    const dim3 grid((unsigned)cdiv((long)q.nz * q.M, SK_ROWS)), block(256);
     if (dtype != D3F_BF16)
       hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, grid, block, 0, stream, q);
     else

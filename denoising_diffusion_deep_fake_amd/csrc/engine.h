@@ -45,6 +45,13 @@ struct Unit {
   size_t coef_off = 0;  // bytes: mean[C] invstd[C] scale[C] shift[C] k[3C]
   int segment = 0;      // backward bucket this unit belongs to
   size_t dy_off = 0;    // this unit's own dY buffer (kept until its weight-gradient group has run)
+  // decoder conv(cat(upsample2x(in0), in1)) with the up-sampling folded into pre-summed weights (pointwise.hip,
+  // pack_up_kernel): per-class forward matrices, the 4x4 stride-2 data gradient w.r.t. in0 (written at in0's own
+  // resolution: no full-resolution scratch, no 2x2 sum) and the skip tensor's 3x3 data gradient as its own launch
+  bool upfold = false;
+  size_t wfc_off = 0, wd4_off = 0, wds_off = 0;
+  int C0Rows = 0, C1Rows = 0;
+  ConvParams dgrad_lo{};
   int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)
   ConvParams fwd{}, dgrad{};
   WgradParams wg{};
@@ -135,6 +142,12 @@ class UnetEngine {
   mutable hipStream_t side_ = nullptr;
   mutable std::vector<hipEvent_t> ev_dy_;  // one per weight-gradient launch of a backward pass
   mutable hipEvent_t ev_join_ = nullptr;
+  // third stream: the decoder's skip-tensor data gradients.  They are consumed by the encoder stages, i.e. a whole
+  // decoder later, so they leave the dependent chain and fill the machine next to its BatchNorm kernels
+  mutable hipStream_t aux_ = nullptr;
+  mutable hipEvent_t ev_aux_ = nullptr;
+  mutable std::vector<hipEvent_t> ev_auxdy_;
+  size_t splitk_aux_off = 0, splitk_aux_bytes = 0;
   // predict_u8 graph: private capture/launch stream + the pointers and constants the captured graph bakes in
   int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
   int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,

@@ -143,6 +143,15 @@ int UnetEngine::add_unit(const std::string& conv_name, const std::string& bn_nam
     u.CinRows = (int)round_up(u.Cin(), 16);
     u.wd_off = alloc((size_t)u.CinRows * u.KpadD * wsize());
   }
+  static const bool no_upfold = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob: gather through the up-sampling
+  u.upfold = !no_upfold && upfold_applies(dtype, up0, k, stride, pad, u.C0, u.C1);
+  if (u.upfold) {
+    u.C0Rows = (int)round_up(u.C0, 16);
+    u.C1Rows = (int)round_up(u.C1, 16);
+    u.wfc_off = alloc((size_t)4 * u.CoutPad * (4 * u.C0 + 9 * u.C1) * wsize());
+    u.wd4_off = alloc((size_t)u.C0Rows * 16 * u.CoutD * wsize());
+    u.wds_off = alloc((size_t)std::max(1, u.C1Rows) * round_up(9L * u.CoutD, bke()) * wsize());
+  }
   units.push_back(u);
   return (int)units.size() - 1;
 }
@@ -156,28 +165,36 @@ int UnetEngine::plan_unit(Unit& u) {
   f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;
   f.M = B * u.Ho * u.Wo;
   f.mode = u.bn ? CONV_RAW_STATS : CONV_HEAD_NCHW;
+  const long rows_full = (long)B * u.Ho * u.Wo;
+  if (u.upfold) {  // rows = one output-parity class; src0 described at its own (low) resolution
+    f.par = 3;
+    f.shift0 = 0;
+    f.Ho = f.H0s; f.Wo = f.W0s;
+    f.M = B * f.H0s * f.W0s;
+    f.Kpad = 4 * u.C0 + 9 * u.C1;
+  }
   if (int rc = conv_igemm_plan(f, cdtype, true)) return rc;
   if (conv_splitk_floats(f) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(f) * sizeof(float);
-  const double macs = (double)f.M * u.Cout * u.KH * u.KW * u.CinReal;
+  const double macs = (double)rows_full * u.Cout * u.KH * u.KW * u.CinReal;  // algorithmic
   f.flops = 2.0 * macs;
   fwd_flops += 2.0 * macs;
   bwd_flops += 2.0 * macs;  // weight gradient
   if (u.bn) {
     const size_t sb = (size_t)f.stat_rows * u.CoutPad * 2 * sizeof(float);
     if (sb > stats_bytes) stats_bytes = sb;
-    const size_t pb = (size_t)bn_bwd_reduce_blocks((long)f.M, u.Cout, dtype) * u.Cout * 2 * sizeof(float);
+    const size_t pb = (size_t)bn_bwd_reduce_blocks(rows_full, u.Cout, dtype) * u.Cout * 2 * sizeof(float);
     if (pb > bnpart_bytes) bnpart_bytes = pb;
   }
-  const size_t dyb = (size_t)f.M * u.CoutD * esize();
+  const size_t dyb = (size_t)rows_full * u.CoutD * esize();
   if (dyb > dy_bytes) dy_bytes = dyb;
   if (!u.apply && u.bn && dyb > dz_bytes) dz_bytes = dyb;
 
   WgradParams& g = u.wg;
   std::memset(&g, 0, sizeof(g));
   g.B = B; g.Hv = u.Hv; g.Wv = u.Wv; g.C0 = u.C0; g.C1 = u.C1;
-  g.H0s = f.H0s; g.W0s = f.W0s; g.shift0 = u.up0;
+  g.H0s = u.Hv >> u.up0; g.W0s = u.Wv >> u.up0; g.shift0 = u.up0;
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
-  g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = f.M;
+  g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = (int)rows_full;
   g.flops = 2.0 * macs;
   if (int rc = wgrad_plan(g, dtype)) return rc;  // single-layer plan; identical layers are re-planned as a group in build()
   {
@@ -186,7 +203,39 @@ int UnetEngine::plan_unit(Unit& u) {
   }
   u.dy_off = alloc(dyb);
 
-  if (u.need_dgrad) {
+  if (u.need_dgrad && u.upfold) {
+    // (1) gradient w.r.t. the low-resolution source: 4x4 stride-2 pad-1 convolution over dY with pre-summed weights
+    ConvParams& l = u.dgrad_lo;
+    std::memset(&l, 0, sizeof(l));
+    l.B = B; l.C0 = u.CoutD; l.C1 = 0;
+    l.Hv = l.H0s = u.Hv; l.Wv = l.W0s = u.Wv;
+    l.Ho = u.Hv / 2; l.Wo = u.Wv / 2;
+    l.Cout = u.C0; l.CoutPad = u.C0Rows; l.Kpad = 16 * u.CoutD;
+    l.KH = l.KW = 4; l.stride = 2; l.pad = 1;
+    l.M = B * l.Ho * l.Wo;
+    l.mode = CONV_DGRAD;
+    l.out_c0 = u.C0;
+    if (int rc = conv_igemm_plan(l, cdtype, true)) return rc;
+    if (conv_splitk_floats(l) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(l) * sizeof(float);
+    l.flops = 2.0 * macs * u.C0 / u.Cin();
+    // (2) gradient w.r.t. the skip tensor: an ordinary 3x3 data gradient with C1 outputs
+    ConvParams& d = u.dgrad;
+    std::memset(&d, 0, sizeof(d));
+    if (u.C1 > 0) {
+      d.B = B; d.C0 = u.CoutD; d.C1 = 0;
+      d.Hv = d.H0s = d.Ho = u.Hv; d.Wv = d.W0s = d.Wo = u.Wv;
+      d.Cout = u.C1; d.CoutPad = u.C1Rows; d.Kpad = u.KpadD;
+      d.KH = d.KW = 3; d.stride = 1; d.pad = 1;
+      d.M = (int)rows_full;
+      d.mode = CONV_DGRAD;
+      d.out_c0 = u.C1;
+      if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
+      // its own split-K scratch: this launch runs on the auxiliary stream, concurrently with the main chain's
+      if (conv_splitk_floats(d) * sizeof(float) > splitk_aux_bytes) splitk_aux_bytes = conv_splitk_floats(d) * sizeof(float);
+      d.flops = 2.0 * macs * u.C1 / u.Cin();
+    }
+    bwd_flops += 2.0 * macs;
+  } else if (u.need_dgrad) {
     ConvParams& d = u.dgrad;
     std::memset(&d, 0, sizeof(d));
     const int s2 = u.stride == 2 ? 1 : 0;
@@ -307,7 +356,12 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
     op.kind = BW_UNIT; op.unit = ui; op.dA = dA; op.mask = mask; op.dres = dres; op.dres_acc = dres_acc;
     op.segment = u.segment;
     if (u.need_dgrad) {
-      if (u.up0) {
+      if (u.upfold) {  // two launches: low-resolution source (dst0) and skip tensor (dst1), both written directly
+        op.dst0 = grad_dst(u.in0, &op.acc0);
+        if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
+        // backward() runs the skip gradients on its auxiliary stream and joins it on leaving bucket 0
+        D3F_CHECK(u.segment == 0, "plan: unit %s: a folded up-sampling layer outside the decoder bucket", u.conv_name.c_str());
+      } else if (u.up0) {
         op.dst0_is_full_scratch = true;
         if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
       } else {
@@ -315,7 +369,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       }
     }
     bwd_ops.push_back(op);
-    if (u.need_dgrad && u.up0) {
+    if (u.need_dgrad && u.up0 && !u.upfold) {
       BwdOp s;
       s.kind = BW_SUM2X2; s.unit = ui; s.C = u.C0; s.Hl = u.Hv / 2; s.Wl = u.Wv / 2; s.segment = u.segment;
       bool acc;
@@ -359,31 +413,40 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   }
   if (int rc = emit_unit(conv1, grad_of[f1], true, -1, false)) return rc;
 
-  // ---- BatchNorm-backward reduce fusion (f32 storage): op j's data gradient -> next unit op's reduction ----
+  // ---- BatchNorm-backward reduce fusion (f32 storage): the data gradient that is the LAST writer of an activation
+  // gradient also emits the (dbeta, dgamma) partial sums of the unit that consumes it -- when that unit is the very
+  // next op (bnpart is one stream-ordered scratch).  The producer may accumulate (it sums first, then reduces the
+  // final values); a consumer with a residual add takes its ReLU mask from its activation instead of from y.
   if (dtype == D3F_F32 && getenv("D3F_NO_FUSED_BN_REDUCE") == nullptr) {
-    auto writers = [&](int gid) {
-      int n = 0;
-      for (const BwdOp& o : bwd_ops) {
-        if ((o.kind == BW_UNIT || o.kind == BW_HEAD) && units[o.unit].need_dgrad && !o.dst0_is_full_scratch && o.dst0 == gid) ++n;
-        if ((o.kind == BW_UNIT || o.kind == BW_HEAD) && o.dst1 == gid) ++n;
-        if (o.kind == BW_UNIT && o.dres == gid) ++n;
-        if ((o.kind == BW_SUM2X2 || o.kind == BW_POOL) && o.dst0 == gid) ++n;
+    auto writes = [&](const BwdOp& o, int gid) {
+      if (o.kind == BW_UNIT || o.kind == BW_HEAD) {
+        if (units[o.unit].need_dgrad && !o.dst0_is_full_scratch && o.dst0 == gid) return true;
+        if (o.dst1 == gid) return true;
+        if (o.kind == BW_UNIT && o.dres == gid) return true;
       }
-      return n;
+      return (o.kind == BW_SUM2X2 || o.kind == BW_POOL) && o.dst0 == gid;
     };
+    static const bool old_rule = getenv("D3F_FUSE_SINGLE_WRITER_ONLY") != nullptr;  // debugging knob: round-1 rule
     for (size_t j = 0; j + 1 < bwd_ops.size(); ++j) {
       BwdOp& pj = bwd_ops[j];
       if (!(pj.kind == BW_UNIT || pj.kind == BW_HEAD)) continue;
       const Unit& up = units[pj.unit];
-      if (!up.need_dgrad || up.dgrad.par || pj.dst0_is_full_scratch || pj.dst1 >= 0 || pj.acc0 || pj.dst0 < 0) continue;
+      const ConvParams& pd = up.upfold ? up.dgrad_lo : up.dgrad;  // the launch that writes dst0
+      if (!up.need_dgrad || pd.par || pj.dst0_is_full_scratch || (pj.dst1 >= 0 && !up.upfold) || pj.dst0 < 0) continue;
       BwdOp& ck = bwd_ops[j + 1];  // the consumer must be the very next op (bnpart is a stream-ordered scratch)
-      if (ck.kind != BW_UNIT || ck.dA != pj.dst0 || writers(pj.dst0) != 1) continue;
+      if (ck.kind != BW_UNIT || ck.dA != pj.dst0) continue;
+      bool last = true;  // no later writer, and (a dres write of op j itself happens BEFORE its data gradient)
+      for (size_t k = j + 1; k < bwd_ops.size(); ++k) last = last && !writes(bwd_ops[k], pj.dst0);
+      int nw = 0;
+      for (const BwdOp& o : bwd_ops) nw += writes(o, pj.dst0) ? 1 : 0;
       const Unit& uc = units[ck.unit];
-      if (!(uc.bn && ck.mask && uc.res_tensor < 0 && uc.res_unit < 0)) continue;
-      D3F_CHECK(up.dgrad.Cout == uc.Cout && up.dgrad.M == B * uc.Ho * uc.Wo && up.dgrad.out_c0 == up.dgrad.Cout,
+      const bool residual = uc.res_tensor >= 0 || uc.res_unit >= 0;
+      if (!last || !(uc.bn && ck.mask)) continue;
+      if (old_rule && (nw != 1 || pj.acc0 || residual)) continue;
+      D3F_CHECK(pd.Cout == uc.Cout && pd.M == B * uc.Ho * uc.Wo && pd.out_c0 == pd.Cout,
                 "plan: fused BatchNorm reduce shape mismatch (%s -> %s)", up.conv_name.c_str(), uc.conv_name.c_str());
       pj.fuse_for_unit = ck.unit;
-      ck.fused_rows = up.dgrad.splitk > 1 ? up.dgrad.stat_rows : up.dgrad.tiles_m;
+      ck.fused_rows = pd.splitk > 1 ? pd.stat_rows : pd.tiles_m;
       bnpart_bytes = std::max(bnpart_bytes, (size_t)ck.fused_rows * uc.Cout * 2 * sizeof(float));
     }
   }
@@ -440,6 +503,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   wpart_off = alloc(wpart_bytes);
   bsum_off = alloc((size_t)classes * CS_PARTS * sizeof(float));
   splitk_off = alloc(splitk_bytes);
+  splitk_aux_off = alloc(splitk_aux_bytes);
   head_nchw_off = alloc((size_t)B * classes * H * W * sizeof(float));  // predict_u8: head output before K16 post
   workspace_bytes = ws_top;
 
@@ -479,6 +543,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
   t.n = 0;
   uint32_t blocks = 0;
   for (const Unit& u : units) {
+    if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
     PackEntry& e = t.e[t.n++];
     const int CoutD = (int)round_up(u.Cout, ve);
     const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
@@ -506,7 +571,15 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     e.ctiles = (uint16_t)((crows + CT - 1) / CT);
     blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
   }
-  return pack_all_launch(cdtype, params_, ws_, t, (int)blocks, s);
+  if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, s)) return rc;
+  char* ws = reinterpret_cast<char*>(ws_);
+  for (const Unit& u : units)
+    if (u.upfold)
+      if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
+                                  u.need_dgrad ? ws + u.wd4_off : nullptr, u.C0Rows,
+                                  (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, s))
+        return rc;
+  return 0;
 }
 
 static inline float* coef_ptr(char* ws, const Unit& u, int which) {
@@ -552,7 +625,7 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
     ConvParams p = u.fwd;
     p.src0 = T(u.in0);
     p.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
-    p.w = ws + u.wf_off;
+    p.w = ws + (u.upfold ? u.wfc_off : u.wf_off);
     if (!u.bn) {  // segmentation head
       p.mode = CONV_HEAD_NCHW;
       p.out0 = out;
@@ -567,7 +640,8 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       p.stats = reinterpret_cast<float*>(ws + stats_off);
       p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
-      if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, (long)p.M,
+      const long rows = (long)B * u.Ho * u.Wo;  // (p.M counts one output-parity class for a folded layer)
+      if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, rows,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
                                       coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s))
@@ -577,7 +651,7 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
                                      u.res_tensor >= 0 ? T(u.res_tensor) : nullptr,
                                      ds ? T(ds->y) : nullptr, ds ? coef_ptr(ws, *ds, 2) : nullptr,
                                      ds ? coef_ptr(ws, *ds, 3) : nullptr, u.relu ? 1 : 0, T(u.a),
-                                     (long)p.M, u.Cout, s))
+                                     rows, u.Cout, s))
           return rc;
       }
     } else {
@@ -667,6 +741,10 @@ UnetEngine::~UnetEngine() {
   for (hipEvent_t e : ev_dy_)
     if (e) (void)hipEventDestroy(e);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
+  for (hipEvent_t e : ev_auxdy_)
+    if (e) (void)hipEventDestroy(e);
+  if (ev_aux_) (void)hipEventDestroy(ev_aux_);
+  if (aux_) (void)hipStreamDestroy(aux_);
   if (side_) (void)hipStreamDestroy(side_);
 }
 
@@ -701,13 +779,27 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
     D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
     D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    D3F_HIP(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
+    D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
   }
+  // opt-in (D3F_AUX_STREAM=1): measured 1 % SLOWER than keeping the skip gradients on the caller's stream -- a third
+  // stream of MFMA-bound work slows the dependent chain's own kernels more than the moved launches save
+  static const bool want_aux = getenv("D3F_AUX_STREAM") != nullptr && atoi(getenv("D3F_AUX_STREAM")) != 0;
+  const bool use_aux = !serial && want_aux;
+  size_t next_aux = 0;
+  bool aux_used = false, aux_joined = false;
   hipStream_t ws_stream = serial ? s : side_;
   float* wpart = reinterpret_cast<float*>(ws + wpart_off);
   size_t next_event = 0;
   bool side_used = false;
   for (const BwdOp& op : bwd_ops) {
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
+    if (aux_used && !aux_joined && op.segment != 0) {
+      // leaving the decoder bucket: the encoder stages read and accumulate into the skip tensors' gradients
+      D3F_HIP(hipEventRecord(ev_aux_, aux_));
+      D3F_HIP(hipStreamWaitEvent(s, ev_aux_, 0));
+      aux_joined = true;
+    }
     if (op.kind == BW_SUM2X2) {
       if (int rc = sum2x2_launch(dtype, ws + dfull_off, G(op.dst0), B, op.Hl, op.Wl, op.C, s)) return rc;
       continue;
@@ -790,7 +882,49 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         return rc;
     }
     // data gradient (main stream)
-    if (u.need_dgrad && !skip_d) {
+    if (u.need_dgrad && !skip_d && u.upfold) {
+      // up-sampling folded into the weights: the gradient of the low-resolution source is a 4x4 stride-2 convolution
+      // over dY written at its own resolution (it feeds the next BatchNorm backward: first), the skip tensor's
+      // gradient an ordinary 3x3 data gradient
+      ConvParams l = u.dgrad_lo;
+      l.src0 = dy;
+      l.w = ws + u.wd4_off;
+      l.out0 = G(op.dst0);
+      l.acc0 = op.acc0 ? 1 : 0;
+      l.partial = l.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+      if (op.fuse_for_unit >= 0) {
+        const Unit& uc = units[op.fuse_for_unit];
+        l.bn_y = T(uc.y);
+        l.bn_coef = coef_ptr(ws, uc, 0);
+        l.bn_partial = reinterpret_cast<float*>(ws + bnpart_off);
+        l.bn_a = (uc.res_tensor >= 0 || uc.res_unit >= 0) ? T(uc.a) : nullptr;
+      }
+      if (int rc = conv_igemm_launch(l, cdtype, s)) return rc;
+      if (op.dst1 >= 0) {
+        // the skip tensor's gradient is not read before the encoder stages: auxiliary stream, joined at the end of
+        // this call (the decoder is one gradient bucket, its skip gradients are consumed by later ones)
+        hipStream_t ds = s;
+        if (use_aux) {
+          if (next_aux == ev_auxdy_.size()) {
+            hipEvent_t e = nullptr;
+            D3F_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_auxdy_.push_back(e);
+          }
+          D3F_HIP(hipEventRecord(ev_auxdy_[next_aux], s));  // dY (and, for an accumulate, every earlier writer) done
+          D3F_HIP(hipStreamWaitEvent(aux_, ev_auxdy_[next_aux], 0));
+          ++next_aux;
+          aux_used = true;
+          ds = aux_;
+        }
+        ConvParams d = u.dgrad;
+        d.src0 = dy;
+        d.w = ws + u.wds_off;
+        d.out0 = G(op.dst1);
+        d.acc0 = op.acc1 ? 1 : 0;
+        d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + (use_aux ? splitk_aux_off : splitk_off)) : nullptr;
+        if (int rc = conv_igemm_launch(d, cdtype, ds)) return rc;
+      }
+    } else if (u.need_dgrad && !skip_d) {
       ConvParams d = u.dgrad;
       d.src0 = dy;
       d.w = ws + u.wd_off;
@@ -811,6 +945,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         d.bn_y = T(uc.y);
         d.bn_coef = coef_ptr(ws, uc, 0);
         d.bn_partial = reinterpret_cast<float*>(ws + bnpart_off);
+        d.bn_a = (uc.res_tensor >= 0 || uc.res_unit >= 0) ? T(uc.a) : nullptr;
       }
       if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
     }
@@ -818,6 +953,10 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream
     D3F_HIP(hipEventRecord(ev_join_, side_));
     D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+  }
+  if (aux_used && !aux_joined) {
+    D3F_HIP(hipEventRecord(ev_aux_, aux_));
+    D3F_HIP(hipStreamWaitEvent(s, ev_aux_, 0));
   }
   return 0;
 }

@@ -80,6 +80,12 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
                         void* wf, int CoutPad, int Kpad, void* wd, int CinRows, int KpadD, int stride,
                         hipStream_t stream);
 
+// conv(cat(upsample2x(x), skip)) with the up-sampling folded into pre-summed weights (pointwise.hip): per-class
+// forward matrices wfc [4][CoutPad][4*C0 + 9*C1], the 4x4 stride-2 data-gradient matrix wd4 [C0Rows][16*CoutD]
+// (gradient w.r.t. the low-resolution source) and the skip tensor's 3x3 data-gradient matrix wds [C1Rows][9*CoutD]
+int pack_up_launch(int dtype, const float* w, int Cout, int C0, int C1, void* wfc, int CoutPad, void* wd4,
+                   int C0Rows, void* wds, int C1Rows, hipStream_t stream);
+
 // every layer of a network in one launch (engine): table passed by value as a kernel argument
 constexpr int PACK_NT = 32;        // filters per tile
 constexpr int PACK_LDS_ROW = 288;  // floats per filter in a tile: CT channels x taps  (32 x 9)

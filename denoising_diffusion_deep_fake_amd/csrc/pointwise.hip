@@ -838,6 +838,107 @@ int pack_weights_launch(int dtype, const float* w, int Cout, int CinReal, int Ci
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// "Up-sample folded into the weights" layouts for the decoder's conv(cat(upsample2x(x), skip)), 3x3 pad 1:
+// nearest x2 up-sampling repeats every low-resolution pixel 2x2 times, so inside an output-parity class (py, px)
+// the 3x3 taps on the up-sampled operand touch only a 2x2 neighbourhood of x, each low-resolution pixel through
+// 1, 2 or 4 taps whose weights can be summed ONCE per step instead of multiplied separately for every pixel:
+// 4 MACs per (pixel, channel pair) instead of 9 on the up-sampled channels, forward and data gradient.
+//   forward, per class z = 2*py + px:  wfc[z][n][(a*2+b)*C0 + c]      = sum_{kh in S(py,a), kw in S(px,b)} w[n][c][kh][kw]
+//                                      wfc[z][n][4*C0 + (kh*3+kw)*C1 + c1] = w[n][C0 + c1][kh][kw]          (skip taps)
+//     S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}; low-resolution row of tap a is j + a + py - 1
+//   data gradient w.r.t. x (a 4x4 stride-2 pad-1 convolution over dY, written at low resolution):
+//                                      wd4[c][(u*4+v)*CoutD + n]      = sum_{kh in T(u), kw in T(v)} w[n][c][kh][kw]
+//     T(0) = {2}, T(1) = {1,2}, T(2) = {0,1}, T(3) = {0}
+//   data gradient w.r.t. the skip tensor (an ordinary 3x3 data gradient with C1 outputs, flipped taps):
+//                                      wds[c1][f*CoutD + n]            = w[n][C0 + c1][8 - f]
+// The sums are formed in fp32 from the fp32 masters (one rounding per sum: the same order of error as the fp32
+// accumulation order inside any conv kernel).  One thread per output element; ~9 M elements per step in total.
+__device__ __forceinline__ unsigned up_fwd_set(int parity, int a) {  // bitmask over kh / kw
+  return parity == 0 ? (a == 0 ? 1u : 6u) : (a == 0 ? 3u : 4u);
+}
+__device__ __forceinline__ unsigned up_bwd_set(int u) { return u == 0 ? 4u : u == 1 ? 6u : u == 2 ? 3u : 1u; }
+
+template <typename T, bool X3>
+__global__ __launch_bounds__(256) void pack_up_kernel(const float* __restrict__ w, int Cout, int C0, int C1,
+                                                      T* __restrict__ wfc, int CoutPad, T* __restrict__ wd4,
+                                                      int C0Rows, T* __restrict__ wds, int C1Rows, int CoutD,
+                                                      int K9) {  // K9: wds row length, 9*CoutD padded to whole k-tiles
+  const int Cin = C0 + C1;
+  const int Kc = 4 * C0 + 9 * C1, K4 = 16 * CoutD;
+  const long nf = 4L * CoutPad * Kc, nd = (long)C0Rows * K4, ns = (long)C1Rows * K9;
+  const long fplane = (long)CoutPad * Kc;  // x3: planes of one class
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nd + ns; i += (long)gridDim.x * 256) {
+    if (i < nf) {
+      const int z = (int)(i / fplane);
+      const long r = i - (long)z * fplane;
+      const int n = (int)(r / Kc), k = (int)(r % Kc);
+      float v = 0.f;
+      if (n < Cout) {
+        if (k < 4 * C0) {
+          const int ab = k / C0, c = k - ab * C0;
+          const unsigned sh = up_fwd_set(z >> 1, ab >> 1), sw = up_fwd_set(z & 1, ab & 1);
+          const float* __restrict__ wp = w + ((long)n * Cin + c) * 9;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              if (((sh >> kh) & 1u) && ((sw >> kw) & 1u)) v += wp[kh * 3 + kw];
+        } else {
+          const int kk = k - 4 * C0, tap = kk / C1, c1 = kk - tap * C1;
+          v = w[((long)n * Cin + C0 + c1) * 9 + tap];
+        }
+      }
+      // class blocks are [z][plane][CoutPad][Kc] in x3 mode, [z][CoutPad][Kc] otherwise
+      pack_store<T, X3>(wfc + (X3 ? 3L * z * fplane : (long)z * fplane), r, fplane, v);
+    } else if (i >= nf + nd) {
+      const long j = i - nf - nd;
+      const int c1 = (int)(j / K9), k = (int)(j % K9);
+      const int f = k / CoutD, n = k - f * CoutD;
+      float v = 0.f;
+      if (c1 < C1 && n < Cout && f < 9) v = w[((long)n * Cin + C0 + c1) * 9 + (8 - f)];
+      pack_store<T, X3>(wds, j, ns, v);
+    } else {
+      const long j = i - nf;
+      const int c = (int)(j / K4), k = (int)(j % K4);
+      const int uv = k / CoutD, n = k - uv * CoutD;
+      float v = 0.f;
+      if (c < C0 && n < Cout) {
+        const unsigned sh = up_bwd_set(uv >> 2), sw = up_bwd_set(uv & 3);
+        const float* __restrict__ wp = w + ((long)n * Cin + c) * 9;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            if (((sh >> kh) & 1u) && ((sw >> kw) & 1u)) v += wp[kh * 3 + kw];
+      }
+      pack_store<T, X3>(wd4, j, nd, v);
+    }
+  }
+}
+
+int pack_up_launch(int dtype, const float* w, int Cout, int C0, int C1, void* wfc, int CoutPad, void* wd4,
+                   int C0Rows, void* wds, int C1Rows, hipStream_t stream) {
+  const int ve = dtype == D3F_BF16 ? 8 : 4;
+  const int CoutD = (int)round_up(Cout, ve);
+  if (wd4 == nullptr) C0Rows = 0;
+  if (wds == nullptr) C1Rows = 0;
+  const int K9 = (int)round_up(9L * CoutD, dtype == D3F_BF16 ? 64 : 32);  // = the data gradient's KpadD
+  const long total = 4L * CoutPad * (4 * C0 + 9 * C1) + (long)C0Rows * 16 * CoutD + (long)C1Rows * K9;
+  if (total == 0) return 0;
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL((pack_up_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
+                       (float*)wfc, CoutPad, (float*)wd4, C0Rows, (float*)wds, C1Rows, CoutD, K9);
+  else if (dtype == D3F_F32X3)
+    hipLaunchKernelGGL((pack_up_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
+                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9);
+  else
+    hipLaunchKernelGGL((pack_up_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
+                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
 // All layers of a network in one launch: the table travels as a kernel argument (no device-side state) and a
 // block looks its layer up by its first block index.  A block transposes one [32 filters][CT channels][taps]
 // tile through LDS: the torch layout [n][c][tap] is read in contiguous runs of CT*taps floats and both packed

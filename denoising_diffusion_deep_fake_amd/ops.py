@@ -78,15 +78,34 @@ def conv_forward(d, src0, src1, wf, dtype=F32, want_stats=True, splitk=False):
     return y, stats, tiles.value
 
 
+def conv_upsample_folded(d, dtype=F32):
+    """does this conv(cat(upsample2x(src0), src1)) run with the up-sampling folded into pre-summed weights?"""
+    return bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))
+
+
 def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False, splitk=False):
+    """(dx0, dx1): gradients of src0 and src1.  For an up-sampled src0 (d.upsample0) dx0 is the gradient of the
+    LOW-resolution tensor [B, H/2, W/2, C0] -- written directly by the folded 4x4 stride-2 kernel where the layer
+    qualifies, else reduced here from the full-resolution gradient of the up-sampled operand."""
     dev = _dev(dy)
     ws = _conv_ws(d, dtype, 1, dev, splitk)
-    if dx0 is None:
-        dx0 = torch.empty((d.B, d.H, d.W, d.C0), dtype=_tdtype(dtype), device=dev)
+    folded = bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))
+    low = (d.B, d.H // 2, d.W // 2, d.C0)
+    if d.upsample0 and not folded:
+        if acc0 or dx0 is not None:
+            raise ValueError("conv_backward_data: an up-sampled source that is not folded takes no dx0 / acc0")
+        full = torch.empty((d.B, d.H, d.W, d.C0), dtype=_tdtype(dtype), device=dev)
+    elif dx0 is None:
+        full = None
+        dx0 = torch.empty(low if d.upsample0 else (d.B, d.H, d.W, d.C0), dtype=_tdtype(dtype), device=dev)
+    else:
+        full = None
     if dx1 is None and d.C1 > 0:
         dx1 = torch.empty((d.B, d.H, d.W, d.C1), dtype=_tdtype(dtype), device=dev)
-    check(_lib.lib().d3f_conv_backward_data(dtype, C.byref(d), ptr(dy), ptr(wd), ptr(dx0), ptr(dx1),
-                                            int(acc0), int(acc1), ptr(ws), stream_ptr()))
+    check(_lib.lib().d3f_conv_backward_data(dtype, C.byref(d), ptr(dy), ptr(wd), ptr(full if full is not None else dx0),
+                                            ptr(dx1), int(acc0), int(acc1), ptr(ws), stream_ptr()))
+    if full is not None:
+        dx0 = upsample2x_backward(full, dtype)
     return dx0, dx1
 
 

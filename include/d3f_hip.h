@@ -135,8 +135,12 @@ size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which);
 size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int with_workspace, int* tiles);
 int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
                      const void* w_fwd, void* y, float* stats, void* workspace, void* stream);
-/* dx over the conv input: channels [0,C0) -> dx0 (full resolution even when upsample0),
- * [C0,C0+C1) -> dx1; acc*: add to the destination instead of overwriting */
+/* dx over the conv input: channels [0,C0) -> dx0, [C0,C0+C1) -> dx1; acc*: add to the destination instead of
+ * overwriting.  With upsample0, dx0 is the gradient of the LOW-resolution source [B][H/2][W/2][C0] when the layer
+ * runs with the up-sampling folded into pre-summed weights (d3f_conv_upsample_folded() == 1: 3x3, stride 1, pad 1,
+ * whole k-tiles per tap -- every decoder layer of the network), else the full-resolution [B][H][W][C0] gradient of
+ * the up-sampled operand, to be reduced with d3f_upsample2x_backward. */
+int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d);
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
                            void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream);
 /* dw in torch layout [Cout][CinReal][KH][KW] f32 */

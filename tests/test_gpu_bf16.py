@@ -54,11 +54,19 @@ def test_conv_bf16(case):
     y, stats, tiles = ops.conv_forward(d, s0, s1, wf, dtype=ops.BF16, splitk=True)
     assert rel_l2(to_nchw(y.float().cpu()), y_ref) < 4e-3
     st = stats.view(tiles, (Co + 15) // 16 * 16, 2).double().sum(0).cpu()
-    # statistics come from the f32 accumulators, not from the rounded outputs
-    assert rel_l2(st[:Co, 1], (y_ref.detach().double() ** 2).sum((0, 2, 3))) < 1e-5
+    # statistics come from the f32 accumulators, not from the rounded outputs.  Layers with the up-sampling folded
+    # into the weights multiply by bf16(w1 + w2 [+ w3 + w4]) -- one more bf16 rounding of the (pre-rounded) test
+    # weights than the reference's bf16(w1) x + bf16(w2) x; with fp32 master weights both forms round once
+    folded = bool(up) and bool(ops.conv_upsample_folded(d, ops.BF16))
+    assert rel_l2(st[:Co, 1], (y_ref.detach().double() ** 2).sum((0, 2, 3))) < (2e-3 if folded else 1e-5)
     dyh = to_nhwc(dy, (Co + 7) // 8 * 8).bfloat16().cuda()
     dx0, dx1 = ops.conv_backward_data(d, dyh, wd, dtype=ops.BF16, splitk=True)
-    assert rel_l2(to_nchw(dx0.float().cpu()), xin.grad[:, :C0]) < 4e-3
+    want0 = xin.grad[:, :C0]
+    if up:  # an up-sampled source gets its gradient at its own (low) resolution
+        x0r = x0.clone().requires_grad_(True)
+        F.interpolate(x0r, scale_factor=2, mode="nearest").backward(want0)
+        want0 = x0r.grad
+    assert rel_l2(to_nchw(dx0.float().cpu()), want0) < 4e-3
     if C1:
         assert rel_l2(to_nchw(dx1.float().cpu()), xin.grad[:, C0:]) < 4e-3
     dw = ops.conv_backward_weight(d, dyh, s0, s1, dtype=ops.BF16)

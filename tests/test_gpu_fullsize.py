@@ -50,8 +50,8 @@ def test_adjoint_identities(shape, mode):
     dw = ops.conv_backward_weight(d, dy, x0, x1, DT)
     lhs = _dot(y, dy)
     # <x, dX>: the up-sampled source enters through its nearest x2 expansion = sum over the 2x2 block of dX0
-    dx0_low = ops.upsample2x_backward(dx0) if up else dx0
-    via_x = _dot(x0, dx0_low) + (_dot(x1, dx1) if C1 else 0.0)
+    # (an up-sampled source gets its gradient at its own low resolution: ops.conv_backward_data)
+    via_x = _dot(x0, dx0) + (_dot(x1, dx1) if C1 else 0.0)
     via_w = _dot(w, dw)
     scale = max(abs(lhs), (y.double().norm() * dy.double().norm()).item() * 1e-3)
     assert abs(lhs - via_x) < 2e-5 * scale, (lhs, via_x)
@@ -121,8 +121,7 @@ def test_adjoint_identities_bf16_full_size(shape):
     dx0, dx1 = ops.conv_backward_data(d, dy, wd, ops.BF16, splitk=True)
     dw = ops.conv_backward_weight(d, dy, x0, x1, ops.BF16)
     lhs = _dot(y[..., :Co], dy[..., :Co])
-    dx0_low = ops.upsample2x_backward(dx0.float()) if up else dx0
-    via_x = _dot(x0, dx0_low) + (_dot(x1, dx1) if C1 else 0.0)
+    via_x = _dot(x0, dx0) + (_dot(x1, dx1) if C1 else 0.0)
     via_w = _dot(w, dw)
     scale = (y.double().norm() * dy.double().norm()).item()
     assert abs(lhs - via_x) < 1e-3 * scale, (lhs, via_x, scale)

@@ -66,15 +66,19 @@ def _conv_case(ops, B, H, W, C0, C1, Cout, k, stride, pad, up=False, cin_real=No
     if cin_real is None:
         dx0, dx1 = ops.conv_backward_data(d, dy_h, wd, dtype, splitk=splitk)
         dxr = xin.grad
-        assert rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]) < TOL_CONV, ("dgrad0", rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]))
-        if C1:
-            assert rel_l2(to_nchw(dx1.cpu()), dxr[:, C0:]) < TOL_CONV
         if up:
-            low = ops.upsample2x_backward(dx0)
-            # autograd reference of the up-sampling
+            # dx0 = gradient of the LOW-resolution source (4x4 stride-2 kernel with pre-summed weights, or the
+            # full-resolution gradient reduced 2x2): autograd reference of the up-sampling
             x0r = x0.clone().requires_grad_(True)
             F.interpolate(x0r, scale_factor=2, mode="nearest").backward(dxr[:, :C0])
-            assert rel_l2(to_nchw(low.cpu()), x0r.grad) < 1e-6
+            assert rel_l2(to_nchw(dx0.cpu()), x0r.grad) < TOL_CONV, ("dgrad0 (low)", rel_l2(to_nchw(dx0.cpu()), x0r.grad))
+            # the 2x2 sum kernel on its own (backward of nearest up-sampling)
+            full = to_nhwc(dxr[:, :C0].contiguous(), C0).cuda()
+            assert rel_l2(to_nchw(ops.upsample2x_backward(full).cpu()), x0r.grad) < 1e-6
+        else:
+            assert rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]) < TOL_CONV, ("dgrad0", rel_l2(to_nchw(dx0.cpu()), dxr[:, :C0]))
+        if C1:
+            assert rel_l2(to_nchw(dx1.cpu()), dxr[:, C0:]) < TOL_CONV
         # accumulate flag
         base = torch.randn(dx0.shape, generator=g).cuda()
         acc, _ = ops.conv_backward_data(d, dy_h, wd, dtype, dx0=base.clone(), dx1=dx1, acc0=True, splitk=splitk)
