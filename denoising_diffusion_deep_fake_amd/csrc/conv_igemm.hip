@@ -239,7 +239,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr unsigned WSTEP = X3 ? 64u : (unsigned)(Elem<T>::BKE * sizeof(T));  // bytes per k-tile in a weight row
   // fragment reads per k-tile (x3: a k-tile of 32 is two 32x32x16 or one 16x16x32 step)
   constexpr int NS = X3 ? ((MT == 32) ? 2 : 1) : ((MT == 32) ? 4 : 2);
-  static_assert(WGM * WGN == 4, "4 waves");
+  // WGK > 1: in-workgroup split of the k-tile.  The 64x32 (WGK 2) and 32x32 (WGK 4) tiles give the deep layers
+  // (M = B*H*W of a few thousand rows) 512 workgroups WITHOUT cross-workgroup split-K slabs and their reduce launch:
+  // the WGK waves that share an output sub-tile take alternate 16-byte k-chunks of every staged k-tile and their
+  // accumulators are summed through LDS, in wave order, in the epilogue.
+  constexpr int WGK = 4 / (WGM * WGN);
+  static_assert(WGM * WGN * WGK == 4, "4 waves");
+  static_assert(NS % WGK == 0, "the k-chunks of a k-tile must divide among the WGK waves");
   static_assert(TM % MT == 0 && TN % MT == 0, "wave tile");
   static_assert(!X3 || sizeof(T) == 4, "x3 mode splits fp32 operands");
   using M_ = std::conditional_t<X3, MmaX3<MT>, Mma<T, MT>>;
@@ -252,13 +258,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int NSTAGE = DB ? 2 : 1;
   constexpr int STAGE = X3 ? 3 * (BM + BN) * X3_ROW : (BM + BN) * LDS_ROW;
   constexpr int APL = BM * X3_ROW, BPL = BN * X3_ROW;  // x3: dwords per plane
-  constexpr int CTILE = BM * (BN + 4);  // epilogue: the fp32 C tile is staged through the same memory
+  constexpr int CTILE = WGK * BM * (BN + 4);  // epilogue: the fp32 C tile(s) are staged through the same memory
   constexpr int LDS_DW = NSTAGE * STAGE > CTILE ? NSTAGE * STAGE : CTILE;
   __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DW];
 
   D3F_PHASE_BEGIN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int wk = wave / (WGM * WGN), wmn = wave % (WGM * WGN);
+  const int wm = wmn / WGN, wn = wmn % WGN;
   const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int chunk = tid & 7, rbase = tid >> 3;
@@ -571,7 +578,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if constexpr (X3) {
       const uint32_t* Bs = As + 3 * APL;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int ss = 0; ss < NS / WGK; ++ss) {
+        const int s = ss * WGK + wk;
         const int c16 = ((MT == 32) ? (2 * s + fq) : fq) ^ ((fr >> 2) & 3);
         uint4 a[FM][3], b[FN][3];
 #pragma unroll
@@ -605,7 +613,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     } else {
     const uint32_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int ss = 0; ss < NS / WGK; ++ss) {
+      const int s = ss * WGK + wk;
       const int ch = (MT == 32) ? (2 * s + fq) : (4 * s + fq);
       uint4 a[FM], b[FN];
 #pragma unroll
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   };
   auto no_hook = [](int) {};
 
-  constexpr int NMFMA = NS * FM * FN * M_::NINST;
+  constexpr int NMFMA = NS / WGK * FM * FN * M_::NINST;
   constexpr int NPIECE = NVA + NVB;
   constexpr int EVERY = (NMFMA / NPIECE) > 0 ? (NMFMA / NPIECE) : 1;
   // emits the load pieces of tile context x behind the MFMAs of compute(buf)
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       advance();
     };
     auto stage_set = [&](int buf, const uint4 (&A)[NVA], const uint4 (&Bv)[NVB]) { stage_regs(buf, A, Bv); };
-    constexpr int NMF = NS * FM * FN * M_::NINST;
+    constexpr int NMF = NS / WGK * FM * FN * M_::NINST;
     constexpr int NPC = NVA + NVB;
     constexpr int EV = (NMF / NPC) > 0 ? (NMF / NPC) : 1;
     // compute tile from LDS `buf`; the pieces of the next load go behind individual MFMAs
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // dimension -- 4x fewer store instructions than one dword per accumulator register, and the
   // per-channel statistics are column sums of the staged tile.
   constexpr int LDC = BN + 4;
-  static_assert(BM * LDC <= LDS_DW, "C tile must fit in the LDS allocation");
+  static_assert(WGK * BM * LDC <= LDS_DW, "C tile must fit in the LDS allocation");
   float* Cs = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -879,8 +888,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < M_::NREG; ++r)
-        Cs[(wm * TM + i * MT + m_local(r)) * LDC + wn * TN + j * MT + n_l] = acc[i][j][r];
+        Cs[wk * (BM * LDC) + (wm * TM + i * MT + m_local(r)) * LDC + wn * TN + j * MT + n_l] = acc[i][j][r];
   __syncthreads();
+  if constexpr (WGK > 1) {
+    // sum the WGK partial tiles in wave order (fixed order: bitwise reproducible) into tile 0
+    for (int e = tid * 4; e < BM * LDC; e += 256 * 4) {
+      float4 v = *reinterpret_cast<const float4*>(&Cs[e]);
+#pragma unroll
+      for (int k = 1; k < WGK; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(&Cs[k * (BM * LDC) + e]);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      *reinterpret_cast<float4*>(&Cs[e]) = v;
+    }
+    __syncthreads();
+  }
 
   constexpr int VN = BN / 4;                 // 16-byte vectors per tile row
   constexpr int NVEC = BM * VN / 256;        // vectors per thread
@@ -1189,6 +1211,14 @@ static ConvTile pick_tile(const ConvParams& p, bool x3) {
   auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn) * nz; };
   if (co % 128 == 0 && blocks(128, 128) >= 512) return {128, 128};
   if (blocks(128, 64) >= 512) return {128, 64};
+  // deep layers (few thousand rows): tiles with an in-workgroup k split keep >= ~2 workgroups per CU without
+  // cross-workgroup split-K slabs (kernel comment at WGK); the x3 mode has too few k-chunks per k-tile for them
+  static const int ksplit_mode = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : 1;  // tuning knob: 0 off, 1 32x32 only (default: measured equal to 2 in step time, better per-kernel), 2 also 64x32
+  if (!x3 && ksplit_mode > 0 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
+    const long b64 = blocks(64, 64);
+    if (b64 < 192) return {32, 32};
+    if (b64 < 384 && ksplit_mode > 1) return {64, 32};
+  }
   return {64, 64};
 }
 
@@ -1294,6 +1324,11 @@ template <typename T, bool X3> static int launch_t(const ConvParams& p, bool sma
   if (t.BM == 256 && t.BN == 32) return launch_cfg<T, 256, 32, 4, 1, 32, X3>(p, smallc, stream);
   if (t.BM == 128 && t.BN == 128) return launch_cfg<T, 128, 128, 2, 2, 32, X3>(p, smallc, stream);
   if (t.BM == 128 && t.BN == 64) return launch_cfg<T, 128, 64, 2, 2, 32, X3>(p, smallc, stream);
+  if constexpr (!X3) {
+    if (t.BM == 64 && t.BN == 32) return launch_cfg<T, 64, 32, 2, 1, 32, X3>(p, smallc, stream);
+    if (t.BM == 32 && t.BN == 32) return launch_cfg<T, 32, 32, 1, 1, 32, X3>(p, smallc, stream);
+  }
+  D3F_CHECK(t.BM == 64 && t.BN == 64, "conv: no kernel for the %dx%d tile", t.BM, t.BN);
   return launch_cfg<T, 64, 64, 2, 2, 32, X3>(p, smallc, stream);
 }
 
