@@ -144,6 +144,13 @@ class UnetEngine {
   mutable hipEvent_t ev_join_ = nullptr;
   // third stream: the decoder's skip-tensor data gradients.  They are consumed by the encoder stages, i.e. a whole
   // decoder later, so they leave the dependent chain and fill the machine next to its BatchNorm kernels
+  // weight packing off the critical path: the layouts of encoder.conv1 / layer1 / layer2 (5 % of the parameters) are
+  // packed on the caller's stream, the rest on the side stream while those layers already run; the forward pass
+  // waits for it in front of the first later layer
+  int ensure_streams() const;
+  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr;
+  mutable bool pack_pending_ = false;
+  int first_late_unit_ = -1;  // first unit (index into `units`) whose packed weights come from the side stream
   mutable hipStream_t aux_ = nullptr;
   mutable hipEvent_t ev_aux_ = nullptr;
   mutable std::vector<hipEvent_t> ev_auxdy_;

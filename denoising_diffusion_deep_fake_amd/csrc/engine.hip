@@ -342,6 +342,8 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
 
   for (auto& u : units)
     if (int rc = plan_unit(u)) return rc;
+  for (int ui = 0; ui < (int)units.size() && first_late_unit_ < 0; ++ui)
+    if (units[ui].conv_name.rfind("encoder.layer3.", 0) == 0) first_late_unit_ = ui;
 
   // ---- backward schedule (static: first writer writes, later writers accumulate) --------
   auto grad_dst = [&](int tid, bool* acc) {
@@ -536,49 +538,87 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
 }
 
 // ------------------------------------------------------------------------------------------
+int UnetEngine::ensure_streams() const {
+  if (side_ != nullptr) return 0;
+  // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
+  // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
+  // D3F_SIDE_PRIORITY=0 turns it off).  A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
+  // left to the caller's stream) was tried and halves the throughput on this platform.
+  int least = 0, greatest = 0;
+  D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
+  D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
+  D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  D3F_HIP(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
+  D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
+  D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
+  D3F_HIP(hipEventCreateWithFlags(&ev_pack_done_, hipEventDisableTiming));
+  return 0;
+}
+
 int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) const {
   D3F_CHECK((int)units.size() <= PACK_MAX_LAYERS, "pack_weights: %d layers exceed the table", (int)units.size());
   const int ve = dtype == D3F_F32 ? 4 : 8;
-  PackTable t;
-  t.n = 0;
-  uint32_t blocks = 0;
-  for (const Unit& u : units) {
-    if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
-    PackEntry& e = t.e[t.n++];
-    const int CoutD = (int)round_up(u.Cout, ve);
-    const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
-    D3F_CHECK(u.Kpad >= u.KH * u.KW * u.Cin() && (!u.need_dgrad || u.KpadD >= u.KH * u.KW * CoutD),
-              "pack_weights: padded K too small");
-    D3F_CHECK(u.wf_off % 16 == 0 && u.wd_off % 16 == 0 && (u.wf_off >> 4) < 0xffffffffull &&
-                  (u.wd_off >> 4) < 0xffffffffull && nf + nd < 0x7fffffffl && u.Kpad < 65536 && u.KpadD < 65536,
-              "pack_weights: layer out of table range");
-    e.w_off = (uint32_t)u.w_off;
-    e.wf_off16 = (uint32_t)(u.wf_off >> 4);
-    e.wd_off16 = (uint32_t)(u.wd_off >> 4);
-    e.block0 = blocks;
-    e.Cout = (uint16_t)u.Cout; e.CinReal = (uint16_t)u.CinReal; e.Cin = (uint16_t)u.Cin();
-    e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
-    e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
-    e.has_d = u.need_dgrad ? 1 : 0;
-    e.conv_stride = (u.need_dgrad && u.dgrad.par) ? 2 : 1;
-    const int taps = u.KH * u.KW;
-    D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
-    int CT = 32;
-    while (CT * taps > PACK_LDS_ROW) CT >>= 1;
-    const int crows = std::max(u.Cin(), u.need_dgrad ? u.CinRows : 0);
-    const int nrows = std::max(u.CoutPad, u.need_dgrad ? CoutD : 0);
-    e.CT = (uint16_t)CT;
-    e.ctiles = (uint16_t)((crows + CT - 1) / CT);
-    blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
-  }
-  if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, s)) return rc;
+  static const bool sync_pack = getenv("D3F_NO_ASYNC_PACK") != nullptr;  // debugging knob: everything on the caller's stream
+  const bool async = !sync_pack && first_late_unit_ > 0;
   char* ws = reinterpret_cast<char*>(ws_);
-  for (const Unit& u : units)
-    if (u.upfold)
-      if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
-                                  u.need_dgrad ? ws + u.wd4_off : nullptr, u.C0Rows,
-                                  (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, s))
-        return rc;
+  for (int part = 0; part < 2; ++part) {  // 0: the first layers (caller's stream), 1: the rest
+    PackTable t;
+    t.n = 0;
+    uint32_t blocks = 0;
+    for (int ui = 0; ui < (int)units.size(); ++ui) {
+      const Unit& u = units[ui];
+      if ((ui >= first_late_unit_ ? 1 : 0) != part && first_late_unit_ > 0) continue;
+      if (first_late_unit_ <= 0 && part == 1) continue;
+      if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
+      PackEntry& e = t.e[t.n++];
+      const int CoutD = (int)round_up(u.Cout, ve);
+      const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
+      D3F_CHECK(u.Kpad >= u.KH * u.KW * u.Cin() && (!u.need_dgrad || u.KpadD >= u.KH * u.KW * CoutD),
+                "pack_weights: padded K too small");
+      D3F_CHECK(u.wf_off % 16 == 0 && u.wd_off % 16 == 0 && (u.wf_off >> 4) < 0xffffffffull &&
+                    (u.wd_off >> 4) < 0xffffffffull && nf + nd < 0x7fffffffl && u.Kpad < 65536 && u.KpadD < 65536,
+                "pack_weights: layer out of table range");
+      e.w_off = (uint32_t)u.w_off;
+      e.wf_off16 = (uint32_t)(u.wf_off >> 4);
+      e.wd_off16 = (uint32_t)(u.wd_off >> 4);
+      e.block0 = blocks;
+      e.Cout = (uint16_t)u.Cout; e.CinReal = (uint16_t)u.CinReal; e.Cin = (uint16_t)u.Cin();
+      e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
+      e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
+      e.has_d = u.need_dgrad ? 1 : 0;
+      e.conv_stride = (u.need_dgrad && u.dgrad.par) ? 2 : 1;
+      const int taps = u.KH * u.KW;
+      D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
+      int CT = 32;
+      while (CT * taps > PACK_LDS_ROW) CT >>= 1;
+      const int crows = std::max(u.Cin(), u.need_dgrad ? u.CinRows : 0);
+      const int nrows = std::max(u.CoutPad, u.need_dgrad ? CoutD : 0);
+      e.CT = (uint16_t)CT;
+      e.ctiles = (uint16_t)((crows + CT - 1) / CT);
+      blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
+    }
+    hipStream_t ps = s;
+    if (part == 1 && async) {
+      if (int rc = ensure_streams()) return rc;
+      D3F_HIP(hipEventRecord(ev_pack_in_, s));  // the parameter update (and every reader of the old layouts) is done
+      D3F_HIP(hipStreamWaitEvent(side_, ev_pack_in_, 0));
+      ps = side_;
+    }
+    if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
+    if (part == 1 || first_late_unit_ <= 0) {
+      for (const Unit& u : units)  // the folded decoder layers: all late
+        if (u.upfold)
+          if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
+                                      u.need_dgrad ? ws + u.wd4_off : nullptr, u.C0Rows,
+                                      (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, ps))
+            return rc;
+    }
+    if (part == 1 && async) {
+      D3F_HIP(hipEventRecord(ev_pack_done_, side_));
+      pack_pending_ = true;
+    }
+  }
   return 0;
 }
 
@@ -622,6 +662,10 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       continue;
     }
     const Unit& u = units[ui];
+    if (pack_pending_ && ui >= first_late_unit_) {  // packed weights of the later layers come from the side stream
+      D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
+      pack_pending_ = false;
+    }
     ConvParams p = u.fwd;
     p.src0 = T(u.in0);
     p.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
@@ -694,6 +738,10 @@ int UnetEngine::predict_u8(const float* params_, float* bnstats, const uint8_t* 
     s255[c] = stdv[c] * 255.0f;
   }
   if (!use_graph) return predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, s);
+  if (pack_pending_) {  // not inside the capture: the replay stream is ordered after the caller's stream below
+    D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
+    pack_pending_ = false;
+  }
 
   // hipGraph path: at B = 1 the ~100 launches of an eval forward are launch-bound; capture them once
   if (gstream_ == nullptr) {
@@ -744,6 +792,8 @@ UnetEngine::~UnetEngine() {
   for (hipEvent_t e : ev_auxdy_)
     if (e) (void)hipEventDestroy(e);
   if (ev_aux_) (void)hipEventDestroy(ev_aux_);
+  if (ev_pack_in_) (void)hipEventDestroy(ev_pack_in_);
+  if (ev_pack_done_) (void)hipEventDestroy(ev_pack_done_);
   if (aux_) (void)hipStreamDestroy(aux_);
   if (side_) (void)hipStreamDestroy(side_);
 }
@@ -769,19 +819,8 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
 #else
   constexpr bool skip_w = false, skip_d = false, skip_b = false;
 #endif
-  if (!serial && side_ == nullptr) {
-    // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
-    // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
-    // D3F_SIDE_PRIORITY=0 turns it off).  A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
-    // left to the caller's stream) was tried and halves the throughput on this platform.
-    int least = 0, greatest = 0;
-    D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
-    D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
-    D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    D3F_HIP(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
-    D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
-  }
+  if (!serial)
+    if (int rc = ensure_streams()) return rc;
   // opt-in (D3F_AUX_STREAM=1): measured 1 % SLOWER than keeping the skip gradients on the caller's stream -- a third
   // stream of MFMA-bound work slows the dependent chain's own kernels more than the moved launches save
   static const bool want_aux = getenv("D3F_AUX_STREAM") != nullptr && atoi(getenv("D3F_AUX_STREAM")) != 0;
