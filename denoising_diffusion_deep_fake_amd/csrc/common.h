@@ -120,6 +120,7 @@ struct ConvParams {
                        // forward of conv(cat(upsample2x(src0), src1)) with the up-sampling folded into pre-summed
                        // weights: 3 (src0 is then described at its own low resolution H0s x W0s, shift0 = 0)
   int nz;              // classes in the launch (grid.z), filled by plan: 4 for par 1 / 3, else 1
+  int xcd_swizzle;     // XCD-aware workgroup order (filled by plan)
   int KH, KW, stride, pad;
   int M;               // B*Ho*Wo
   int tiles_m, tiles_n;
@@ -181,6 +182,7 @@ struct WgradParams {
   int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;
   int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
+  int xcd_swizzle;  // tap-parallel kernel: XCD-aware workgroup order (filled by plan)
   double flops;  // algorithmic FLOPs of this launch, for profiling
 };
 // Grouped launches: layers of identical shape (the 3x3 stride-1 convolutions inside one ResNet stage) run their

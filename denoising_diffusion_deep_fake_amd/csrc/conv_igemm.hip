@@ -23,6 +23,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -266,7 +267,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WGM * WGN), wmn = wave % (WGM * WGN);
   const int wm = wmn / WGN, wn = wmn % WGN;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  // XCD-aware workgroup order (speed only): consecutive block ids are dealt round-robin over the 8 XCDs (private L2s),
+  // so the tiles_n workgroups that gather the SAME activation rows -- and neighbouring m-tiles, which share halo rows --
+  // each pulled them into a different L2.  The bijective remap (cdna_hip_programming.md T1) gives every XCD a
+  // contiguous range of the logical order (n-tile fastest, then m-tile, k-slice, class).
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_swizzle) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bx = wgid % gx;
+    const unsigned rest = wgid / gx;
+    by = rest % gy;
+    bz = rest / gy;
+  }
+  const int tile_n = (int)bx % p.tiles_n, tile_m = (int)bx / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int chunk = tid & 7, rbase = tid >> 3;
 
@@ -279,9 +295,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // the packed weight rows hold the taps class by class (pointwise.hip: dgrad_tap_slot), so a class is a k-offset.
   int KH_ = p.KH, KW_ = p.KW, Kc = p.Kpad, par_py = 0, par_px = 0;
   unsigned wk0 = 0;  // first weight element (k index) of this launch slice
-  par_class(p.par, (int)blockIdx.z, par_py, par_px);
+  par_class(p.par, (int)bz, par_py, par_px);
   if (p.par == 1) {       // 3x3, pad 1
-    const int z = blockIdx.z;
+    const int z = (int)bz;
     KH_ = 1 + par_py;
     KW_ = 1 + par_px;
     Kc = KH_ * KW_ * p.C0;
@@ -373,8 +389,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const int nk_total = Kc / BKE;
   // split-K: grid.y cuts the k-tile range; each slice writes raw accumulators to its slab
-  const int kt_begin = (int)((long)nk_total * blockIdx.y / p.splitk);
-  const int kt_end = (int)((long)nk_total * (blockIdx.y + 1) / p.splitk);
+  const int kt_begin = (int)((long)nk_total * by / p.splitk);
+  const int kt_end = (int)((long)nk_total * (by + 1) / p.splitk);
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
   int t_kh = 0, t_kw = 0, t_c = 0, t_seg = 0;
   if (FAST == 2) {
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int w_row_bytes = X3 ? p.w_ld * 2 : p.w_ld * (int)sizeof(T);
   // par 3: class z owns the matrix (x3: the three planes) at z * [planes] * CoutPad rows
   const unsigned wk0_bytes = wk0 * (X3 ? 2u : (unsigned)sizeof(T)) +
-                             (p.par == 3 ? (unsigned)blockIdx.z * (unsigned)((X3 ? 3 : 1) * p.CoutPad * w_row_bytes) : 0u);
+                             (p.par == 3 ? bz * (unsigned)((X3 ? 3 : 1) * p.CoutPad * w_row_bytes) : 0u);
   unsigned woff[NVB];
   int x3_bdst[NVB];  // x3: LDS dword offset of this thread's weight pieces inside the B planes (-1: no piece)
 #pragma unroll
@@ -913,7 +929,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   if (p.splitk > 1) {
     // slab rows: class-major virtual rows z * M + m (the reduce kernel maps them to output pixels)
-    float* __restrict__ slab = p.partial + ((long)blockIdx.y * p.nz + blockIdx.z) * p.M * p.Cout;
+    float* __restrict__ slab = p.partial + ((long)by * p.nz + bz) * p.M * p.Cout;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int row = rv0 + i * RSTEP, m = m0 + row;
@@ -977,7 +993,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
         const int nn = n0 + tid;
         if (nn < p.CoutPad) {
-          const long st = (long)blockIdx.z * p.tiles_m + tile_m;  // one partial row per (class, m-tile)
+          const long st = (long)bz * p.tiles_m + tile_m;  // one partial row per (class, m-tile)
           p.stats[(st * p.CoutPad + nn) * 2 + 0] = a1;
           p.stats[(st * p.CoutPad + nn) * 2 + 1] = a2;
         }
@@ -1274,6 +1290,11 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
+  // tuning knob D3F_XCD_SWIZZLE: letters i (this kernel) / w (weight gradient).  Measured: the remap cuts this
+  // kernel's L2-miss traffic by 12 % but makes it 2 % SLOWER (every XCD then works on one contiguous band of rows
+  // and the bands' lengths differ), so it is off here by default and on for the weight gradient only
+  static const char* swz = getenv("D3F_XCD_SWIZZLE");
+  p.xcd_swizzle = (swz != nullptr && strchr(swz, 'i') != nullptr) ? 1 : 0;
   p.splitk = 1;
   p.stat_rows = p.nz * p.tiles_m;
   // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop

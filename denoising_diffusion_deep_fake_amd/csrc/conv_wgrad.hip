@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace d3f {
 
@@ -88,18 +89,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   const int wmn = wave / KSPLIT;
   const int wm = wmn / WGN, wn = wmn % WGN;
 
-  int bid = blockIdx.x;
+  // XCD-aware workgroup order (speed only, never correctness): the (tap, co, ci) workgroups of one pixel slab read
+  // the SAME dY rows and nearly the same X rows, but consecutive block ids are dealt round-robin over the 8 XCDs, each
+  // with its own L2 -- every slab was fetched by up to 8 L2s (layer1: 256 MB per launch against 34 MB of operands).
+  // The bijective remap of cdna_hip_programming.md T1 gives every XCD a contiguous range of the logical order
+  // (x fastest, then slab, then group member), so a slab's workgroups share one L2.
+  int bid = blockIdx.x, split = blockIdx.y, member = blockIdx.z;
+  if (p.xcd_swizzle) {
+    const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bid = (int)(wgid % gx);
+    const unsigned rest = wgid / gx;
+    split = (int)(rest % gridDim.y);
+    member = (int)(rest / gridDim.y);
+  }
   const int tile_ci = bid % p.tiles_ci;
   bid /= p.tiles_ci;
   const int tile_co = bid % p.tiles_co;
   const int tap = bid / p.tiles_co;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;
-  const int split = blockIdx.y;
   const int Cin = p.C0 + p.C1;
 
   // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip); blockIdx.z = group member
-  const int member = blockIdx.z;
   const void* const dy_ptr = grp.dy[member];
   const void* const src0_ptr = grp.src0[member];
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy_ptr, p.dy_bytes);
@@ -460,6 +474,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   if (splits < 1) splits = 1;
   p.chunks_per_split = cdiv(total_chunks, splits);
   p.splits = cdiv(total_chunks, p.chunks_per_split);
+  static const char* swz = getenv("D3F_XCD_SWIZZLE");  // tuning knob: letters i (conv_igemm) / w (this kernel); default w
+  p.xcd_swizzle = (swz == nullptr || strchr(swz, 'w') != nullptr) ? 1 : 0;
   return 0;
 }
 

@@ -8,7 +8,7 @@ import json
 import sys
 
 
-def main(out_dir, json_path):
+def main(out_dir, json_path, head="unknown", date=""):
     path = glob.glob(f"{out_dir}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
@@ -30,8 +30,9 @@ def main(out_dir, json_path):
                      "mfma_mops_f32": c["SQ_INSTS_VALU_MFMA_MOPS_F32"]})
         print(rows[-1])
     json.dump({"source": "profiles/tools/collect_mfma.sh (6 training steps incl. warm-up, 256x256 bs16 f32; kernels "
-                         "serialised by PMC collection)", "kernels": rows}, open(json_path, "w"), indent=1)
+                         "serialised by PMC collection)", "git_head": head, "date": date, "kernels": rows},
+              open(json_path, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])

@@ -1,46 +1,86 @@
-"""Per-launch HBM traffic of the forward conv_igemm launches from the two PMC passes of collect_traffic.sh.
+"""HBM traffic per kernel class from the two PMC passes of collect_traffic.sh, and per launch of the roofline kernel.
 
-Forward launches = the first 47 conv_igemm_kernel dispatches after each noise_blend_kernel dispatch (one training
-step: blend -> forward -> loss -> backward -> Adam).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950
-FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)."""
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section; Infinity-Cache hits are counted as traffic).  Steps are delimited by the
+noise_blend_kernel dispatches (one training step: blend -> forward -> loss -> backward -> Adam); only whole steps are
+used.  Durations come from the kernel trace of the FETCH_SIZE pass (PMC collection serialises kernels: no overlap).
+
+  python3 profiles/tools/traffic_from_pmc.py <out_dir> <traffic.json> <hbm_kernels.json> <git head> <date>"""
+import collections
 import csv
 import glob
 import json
 import sys
 
-N_FWD = 47
+
+def short(name):
+    name = name.replace("void d3f::", "").replace("d3f::", "")
+    return name.split("<")[0].split("(")[0]
 
 
-def per_launch(counter_dir, counter):
+def load(counter_dir, counter):
     path = glob.glob(f"{counter_dir}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    vals, left = [], 0
-    for r in rows:
-        name = r["Kernel_Name"]
-        if "noise_blend_kernel" in name:
-            left = N_FWD
-        elif "conv_igemm_kernel" in name and left > 0:
-            vals.append(float(r["Counter_Value"]))
-            left -= 1
-    return vals
+    return rows
 
 
-def main(out_dir, json_path):
-    f = per_launch(f"{out_dir}/FETCH_SIZE", "FETCH_SIZE")
-    w = per_launch(f"{out_dir}/WRITE_SIZE", "WRITE_SIZE")
-    assert f and len(f) == len(w) and len(f) % N_FWD == 0, (len(f), len(w))
-    fm, wm = sum(f) / len(f), sum(w) / len(w)
-    res = {"kernel": "conv_igemm_kernel (forward launches)", "launches_sampled": len(f),
-           "fetch_size_kb_mean": round(fm, 1), "write_size_kb_mean": round(wm, 1), "fetch_correction": 2.0,
-           "hbm_bytes_per_launch": int(round((2.0 * fm + wm) * 1024)),
-           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace) on `bench.py "
-                     "--steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --no-alt`, 256x256 bs16 f32; bytes = "
-                     "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; "
-                     "profiles/tools/collect_traffic.sh"}
-    json.dump(res, open(json_path, "w"), indent=1)
+def steps_of(rows):
+    """list of steps, each a list of rows, cut at noise_blend_kernel; first partial and last open step dropped"""
+    cuts = [i for i, r in enumerate(rows) if "noise_blend_kernel" in r["Kernel_Name"]]
+    return [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def durations(counter_dir):
+    path = glob.glob(f"{counter_dir}/**/*kernel_trace.csv", recursive=True)
+    if not path:
+        return {}
+    return {int(r["Dispatch_Id"]): (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            for r in csv.DictReader(open(path[0]))}
+
+
+def main(out_dir, traffic_json, kernels_json, head, date):
+    f, w = load(f"{out_dir}/FETCH_SIZE", "FETCH_SIZE"), load(f"{out_dir}/WRITE_SIZE", "WRITE_SIZE")
+    fs, ws = steps_of(f), steps_of(w)
+    n = min(len(fs), len(ws))
+    assert n >= 1, "no whole training step in the PMC passes"
+    fs, ws = fs[-n:], ws[-n:]
+    dur = durations(f"{out_dir}/FETCH_SIZE")
+    agg = collections.OrderedDict()
+    for sf, sw in zip(fs, ws):
+        assert [short(r["Kernel_Name"]) for r in sf] == [short(r["Kernel_Name"]) for r in sw], "passes differ"
+        for rf, rw in zip(sf, sw):
+            a = agg.setdefault(short(rf["Kernel_Name"]), [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(rf["Counter_Value"])
+            a[2] += float(rw["Counter_Value"])
+            a[3] += dur.get(int(rf["Dispatch_Id"]), 0.0)
+    kernels = []
+    for name, (cnt, fk, wk, us) in sorted(agg.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2])):
+        mb = (2.0 * fk + wk) * 1024 / 1e6 / n
+        kernels.append({"kernel": name, "launches_per_step": round(cnt / n, 1), "hbm_MB_per_step": round(mb, 1),
+                        "us_per_step": round(us / n, 1),
+                        "GB_per_s": round(mb / max(us / n, 1e-9) * 1e3, 0) if us else None,
+                        "frac_of_8TBs": round(mb / max(us / n, 1e-9) * 1e3 / 8000.0, 3) if us else None})
+    total = sum(k["hbm_MB_per_step"] for k in kernels)
+    src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/tools/collect_traffic.sh over `bench.py --steps 4 "
+           "--warmup 2 --no-cpu-baseline --no-kernel-events --no-alt` (256x256, bs 16, f32); bytes = (2*FETCH_SIZE + "
+           "WRITE_SIZE) KB per MI355X_MICROARCH.md; durations from the FETCH_SIZE pass (kernels serialised)")
+    json.dump({"source": src, "git_head": head, "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
+               "kernels": kernels}, open(kernels_json, "w"), indent=1)
+    ci = agg["conv_igemm_kernel"]
+    res = {"kernel": "conv_igemm_kernel (ALL launches: forward + data gradient)", "git_head": head, "date": date,
+           "launches_sampled": ci[0], "launches_per_step": round(ci[0] / n, 1),
+           "fetch_size_kb_mean": round(ci[1] / ci[0], 1), "write_size_kb_mean": round(ci[2] / ci[0], 1),
+           "fetch_correction": 2.0, "hbm_bytes_per_launch": int(round((2.0 * ci[1] + ci[2]) * 1024 / ci[0])),
+           "source": src}
+    json.dump(res, open(traffic_json, "w"), indent=1)
     print(json.dumps(res))
+    for k in kernels[:24]:
+        print(f"{k['kernel']:34s} n/step {k['launches_per_step']:6.1f}  {k['hbm_MB_per_step']:9.1f} MB/step  "
+              f"{k['us_per_step']:8.1f} us  {k['GB_per_s']} GB/s")
+    print(f"total {total:.1f} MB/step")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:6])
