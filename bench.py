@@ -322,7 +322,7 @@ def main():
             log("first step done")
     use_events = not args.no_kernel_events
     # An event pair costs ~8 us of stream time (its marker packets drain the queue), so only the launches of the
-    # roofline kernel -- conv_igemm_kernel: 47 forward + 46 data-gradient launches per step -- are bracketed, and only
+    # roofline kernel -- conv_igemm_kernel: 47 forward + ~50 data-gradient launches per step -- are bracketed, and only
     # on every EVERY-th timed step (>= 5 sampled steps whenever K >= 5).  The weight-gradient kernels are timed in a
     # separate pass after the timed region.
     EVERY = max(1, min(8, args.steps // 5))
@@ -404,7 +404,8 @@ def main():
             (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
-                           "kernel": "conv_igemm_kernel, ALL launches (47 forward + 46 data-gradient per step)",
+                           "kernel": f"conv_igemm_kernel, ALL launches ({int(n[0]) // sampled} forward + "
+                                     f"{int(n[1]) // sampled} data-gradient per step)",
                            "launches": int(n_all), "sampled_steps": f"{sampled} of {args.steps} timed steps",
                            "avg_launch_us": round(1e3 * t_all / n_all, 2),
                            "flop_per_launch": round(f_all / n_all, 1),

@@ -1232,8 +1232,8 @@ static ConvTile pick_tile(const ConvParams& p, bool x3) {
   static const int ksplit_mode = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : 1;  // tuning knob: 0 off, 1 32x32 only (default: measured equal to 2 in step time, better per-kernel), 2 also 64x32
   if (!x3 && ksplit_mode > 0 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
     const long b64 = blocks(64, 64);
-    if (b64 < 192) return {32, 32};
-    if (b64 < 384 && ksplit_mode > 1) return {64, 32};
+    if (b64 < 192 || (b64 < 384 && ksplit_mode == 3)) return {32, 32};
+    if (b64 < 384 && ksplit_mode == 2) return {64, 32};
   }
   return {64, 64};
 }
