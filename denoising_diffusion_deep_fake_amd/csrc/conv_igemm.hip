@@ -1229,7 +1229,11 @@ static ConvTile pick_tile(const ConvParams& p, bool x3) {
   if (blocks(128, 64) >= 512) return {128, 64};
   // deep layers (few thousand rows): tiles with an in-workgroup k split keep >= ~2 workgroups per CU without
   // cross-workgroup split-K slabs (kernel comment at WGK); the x3 mode has too few k-chunks per k-tile for them
-  static const int ksplit_mode = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : 1;  // tuning knob: 0 off, 1 32x32 only (default: measured equal to 2 in step time, better per-kernel), 2 also 64x32
+  // tuning knob D3F_KSPLIT_TILES: 0 off; 1 = 32x32 below 192 64x64-tiles, cross-workgroup split-K slabs + reduce up
+  // to 384; 2 = as 1 with 64x32 in between; 3 (default) = 32x32 all the way to 384.  Measured in one call (r02_v):
+  // 3 is 1.2 % faster per step than 1 -- this kernel gets slower (smaller tiles) but the 27 slab-reduce launches
+  // per step and their slab traffic leave the caller's stream
+  static const int ksplit_mode = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : 3;
   if (!x3 && ksplit_mode > 0 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
     const long b64 = blocks(64, 64);
     if (b64 < 192 || (b64 < 384 && ksplit_mode == 3)) return {32, 32};
