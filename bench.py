@@ -385,7 +385,8 @@ def main():
                    "whole_step_frac_of_peak": round(whole / peak, 4)},
     }
     if use_events and n[0] > 0 and n[1] > 0:
-        names = ["conv_igemm_kernel (forward launches)", "conv_igemm_kernel (data-gradient launches)",
+        names = ["conv_igemm_kernel + conv_patch_kernel (forward launches)",
+                 "conv_igemm_kernel + conv_patch_kernel (data-gradient launches)",
                  "conv_wgrad_* (weight-gradient launches)"]
         nsteps = [sampled, sampled, diag]
         per = [{"kernel": names[k], "launches": int(n[k]), "avg_us": round(1e3 * ms[k] / max(n[k], 1), 2),
@@ -404,7 +405,8 @@ def main():
             (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
-                           "kernel": f"conv_igemm_kernel, ALL launches ({int(n[0]) // sampled} forward + "
+                           "kernel": f"conv_igemm_kernel (+ conv_patch_kernel, its LDS-patch form for the 16-channel "
+                                     f"full-resolution layers), ALL launches ({int(n[0]) // sampled} forward + "
                                      f"{int(n[1]) // sampled} data-gradient per step)",
                            "launches": int(n_all), "sampled_steps": f"{sampled} of {args.steps} timed steps",
                            "avg_launch_us": round(1e3 * t_all / n_all, 2),

@@ -141,6 +141,7 @@ struct ConvParams {
   const float* bn_coef;
   float* bn_partial;
   const void* bn_a;    // that layer's activation when its ReLU mask cannot be recomputed from y (residual add) or null
+  int patch;           // 1: runs as conv_patch_kernel (conv_patch.hip; filled by plan)
 };
 
 struct ConvTile {
@@ -164,6 +165,10 @@ static inline bool parity_dgrad_applies(int dtype, int stride, int k, int pad, i
 int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk = false);
 size_t conv_splitk_floats(const ConvParams& p);
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
+// conv_patch.hip: LDS-patch form of the full-resolution 16-channel 3x3 layers (chosen inside conv_igemm_plan)
+bool conv_patch_applies(const ConvParams& p, int dtype);
+void conv_patch_plan(ConvParams& p);
+int conv_patch_launch(const ConvParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // Weight gradient: conv_wgrad.hip

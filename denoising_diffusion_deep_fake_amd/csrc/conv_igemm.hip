@@ -1291,6 +1291,11 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   const long bw = (p.par == 3 ? 4 : 1) * (dtype == D3F_F32X3 ? (long)p.CoutPad * p.Kpad * 6 : (long)p.CoutPad * p.Kpad * es);
   D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
+  p.patch = 0;
+  if (conv_patch_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
+    conv_patch_plan(p);
+    return 0;
+  }
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
@@ -1376,7 +1381,8 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);
   if (prof) prof_begin(prof_cls, q.flops, stream);
-  int rc = dtype == D3F_F32X3 ? launch_t<float, true>(q, smallc, stream)
+  int rc = q.patch            ? conv_patch_launch(q, stream)
+           : dtype == D3F_F32X3 ? launch_t<float, true>(q, smallc, stream)
            : dtype == D3F_F32 ? launch_t<float, false>(q, smallc, stream)
                               : launch_t<bf16_t, false>(q, smallc, stream);
   // the event pair brackets conv_igemm_kernel alone (not its split-K reduce), so that the bench's per-launch

@@ -15,7 +15,8 @@ def main(out_dir, json_path, head="unknown", date=""):
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
         cls = ("conv_igemm" if "conv_igemm" in name else "conv_wgrad_patch" if "conv_wgrad_patch" in name
-               else "conv_wgrad" if "conv_wgrad_kernel" in name else None)
+               else "conv_wgrad" if "conv_wgrad_kernel" in name else "conv_patch" if "conv_patch_kernel" in name
+               else None)
         if cls is None:
             continue
         agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])

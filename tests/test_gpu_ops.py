@@ -98,6 +98,8 @@ CASES = [
     (1, 32, 32, 128, 64, 64, 3, 1, 1, True),     # decoder block 2
     (2, 24, 40, 16, 0, 3, 3, 1, 1, False),       # head shape (3 outputs), ragged 8x16 patch tiles
     (1, 24, 40, 64, 64, 32, 3, 1, 1, True),      # decoder 3 conv1 with ragged patch tiles
+    (2, 8, 64, 16, 0, 16, 3, 1, 1, False),       # full-resolution 16-channel layer: conv_patch_kernel (4x64 tiles)
+    (1, 12, 128, 16, 0, 8, 3, 1, 1, False),      # conv_patch_kernel, two tiles per row, fewer filters than the tile
 ]
 
 
