@@ -11,8 +11,9 @@
 // v_mfma_f32_16x16x4_f32 with compile-time tap offsets: no address arithmetic, no barrier, no k padding (144, not 160).
 //
 //   wave w = output row w of the tile (64 pixels = 4 fragments of 16); per tap: 4 A reads + 1 B read, 16 MFMAs
-//   LDS: patch [6][66][16 + 4] f32 (31.7 KB) + weights [16][144 + 4] f32 (9.5 KB) -> 3 workgroups per CU; the pad
-//   of 4 dwords makes both fragment reads (8 consecutive rows x 16 bytes per pass) bank-conflict free
+//   LDS: patch [6][66][16 + 4] f32 (31.7 KB) + weights [16][144] f32 (9.2 KB) = 40 896 B -> 4 workgroups per CU; the
+//   pixel pad of 4 dwords / the XOR swizzle of the weight chunks make both fragment reads (8 consecutive rows x 16
+//   bytes per pass) bank-conflict free
 //   epilogue: the C tile goes through LDS (aliasing the patch) and out as 16-byte vectors, as in conv_igemm.hip
 #include "common.h"
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
   constexpr int CS = CIN + 4;        // dwords per staged pixel
   constexpr int KR = 9 * CIN;        // real k extent
-  constexpr int WS = KR + 4;         // dwords per staged weight row
+  constexpr int WS = KR;             // dwords per staged weight row (no pad: 16-byte chunks XOR-swizzled by the row)
   constexpr int CV = CIN / 4;        // 16-byte vectors per pixel
   constexpr int NPV = PR * PC * CV;  // patch vectors
   constexpr int NWV = BN * (KR / 4); // weight vectors
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
     const int row = id / (KR / 4), ch = id - row * (KR / 4);
-    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[row * WS + ch * 4]) = wv[i];
+    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[row * WS + (ch ^ ((row >> 1) & 3)) * 4]) = wv[i];
   }
   __syncthreads();
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < FM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
-  const float* Bbase = Wl + fr * WS + fq * 4;
+  const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // a tap's four chunks are permuted by the row
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3, kw = tap - kh * 3;

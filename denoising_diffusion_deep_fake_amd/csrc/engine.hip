@@ -685,6 +685,18 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
       const long rows = (long)B * u.Ho * u.Wo;  // (p.M counts one output-parity class for a folded layer)
+      if (u.apply && bn_fused_finalize_ok(dtype, p.stat_rows, u.Cout)) {
+        // finalize folded into the streaming pass (bn_fused.hip): one launch instead of two
+        if (int rc = bn_finalize_apply_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, rows, params_ + u.g_off,
+                                              params_ + u.b_off, 1e-5f, 0.1f, bnstats + u.rm_off, bnstats + u.rv_off,
+                                              coef_ptr(ws, u, 0), coef_ptr(ws, u, 1), coef_ptr(ws, u, 2),
+                                              coef_ptr(ws, u, 3), T(u.y),
+                                              u.res_tensor >= 0 ? T(u.res_tensor) : nullptr, ds ? T(ds->y) : nullptr,
+                                              ds ? coef_ptr(ws, *ds, 2) : nullptr, ds ? coef_ptr(ws, *ds, 3) : nullptr,
+                                              u.relu ? 1 : 0, T(u.a), rows, s))
+          return rc;
+        continue;
+      }
       if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, rows,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
@@ -878,15 +890,22 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
                                                u.Cout, s, msc, msf)) {
         return rc;
       }
-      if (!skip_b)
+      if (!skip_b && bn_fused_finalize_ok(dtype, nb, u.Cout)) {
+        // finalize folded into the streaming pass (bn_fused.hip)
+        if (int rc = bn_bwd_finalize_apply_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,
+                                                  grads + u.g_off, grads + u.b_off, 0, k, G(op.dA), amask, T(u.y), dy,
+                                                  op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows, s,
+                                                  msc, msf))
+          return rc;
+      } else if (!skip_b) {
         if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
                                             grads + u.g_off, grads + u.b_off, 0, k, s))
           return rc;
-      if (!skip_b)
         if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
                                          op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
                                          u.Cout, s, msc, msf))
           return rc;
+      }
     }
     // weight gradient of the unit's launch group (side stream), once the group's last dY exists
     const WGroup& grp = wgroups[u.wgroup];

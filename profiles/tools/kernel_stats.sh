@@ -23,5 +23,6 @@ STATS=$(find "$OUT" -name 'trace_kernel_stats.csv' | head -1)
 python3 profiles/summarize_trace.py "$TRACE" $((STEPS + WARM)) > "gpurun_out/${TAG}_kernel_stats.csv"
 head -40 "$STATS" > "gpurun_out/${TAG}_rocprof_stats_head.csv"
 python3 profiles/tools/step_timeline.py "$TRACE" > "gpurun_out/${TAG}_step_timeline.txt" 2>&1 || true
+python3 profiles/tools/step_launches.py "$TRACE" > "gpurun_out/${TAG}_step_launches.txt" 2>&1 || true
 tail -3 "$OUT/run.log"
 rm -f "$TRACE"  # tens of MB; the summaries are what is kept
