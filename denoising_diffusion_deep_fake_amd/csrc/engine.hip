@@ -460,7 +460,12 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
     // with nothing to overlap: the cap shrinks towards the end of the pass -- per encoder stage (512, 256, 128, 64
     // output channels = the order the backward pass visits them).  Tuning knobs: D3F_WGRAD_GROUP_CAPS="a,b,c,d",
     // D3F_WGRAD_GROUP_MAX=n (a cap on all of them).
-    int caps[4] = {5, 4, 2, 1};  // measured: equal step time to one launch per layer, fewer slabs
+    // Default since r02_ab/ac/ad: ONE launch per layer (caps 1,1,1,1).  A grouped launch (2880 workgroups of ~140 us
+    // for layer4) fills every wave slot of the chip, and stream priority only decides who gets a FREE slot: the
+    // chain's next 5 us BatchNorm kernel then waited 80-140 us for one (profiles/r02_aa_step_launches.txt).  With the
+    // BatchNorm finalize launches gone from the chain, per-layer launches are 1.3 % faster per step than 5,4,2,1
+    // although they write more slabs.
+    int caps[4] = {1, 1, 1, 1};
     if (const char* gc = getenv("D3F_WGRAD_GROUP_CAPS")) sscanf(gc, "%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3]);
     int group_max = WG_MAXG;
     if (const char* gm = getenv("D3F_WGRAD_GROUP_MAX")) group_max = std::max(1, std::min(WG_MAXG, atoi(gm)));
