@@ -36,6 +36,15 @@ __device__ __forceinline__ void slab_reduce(const float* __restrict__ partial, i
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const float* base = partial + ((long)c0 * 2 + q * 4);
   int r = rl;
+  for (; r + 112 < rows; r += 128) {  // eight rows in flight (layer1-type layers bring 512 partial rows)
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(base + (long)(r + 16 * j) * ld * 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w;
+    }
+  }
   for (; r + 48 < rows; r += 64) {  // four rows in flight
     const float4 v0 = *reinterpret_cast<const float4*>(base + (long)r * ld * 2);
     const float4 v1 = *reinterpret_cast<const float4*>(base + (long)(r + 16) * ld * 2);
