@@ -20,7 +20,10 @@
 namespace d3f {
 
 constexpr int BNF_SC = 32;         // channels per slab = one 128-byte line per tensor row
-constexpr int BNF_MAX_ROWS = 512;  // partial rows a workgroup is asked to reduce (x 256 B)
+constexpr int BNF_MAX_ROWS = 512;
+#ifndef BNF_BWD_U
+#define BNF_BWD_U 2  // rows in flight per thread in the backward streaming pass (4: +0.4 % step time -- 142 VGPRs leave one workgroup per CU next to the weight-gradient stream)
+#endif  // partial rows a workgroup is asked to reduce (x 256 B)
 
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   static const bool off = getenv("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
   if (r1 > rows) r1 = rows;
   const bool from_a = mask_scale == nullptr && a != nullptr;
   const bool rd_dres = dres != nullptr && dres_acc;
-  constexpr int U = 4;
+  constexpr int U = BNF_BWD_U;
   for (long r = r0 + rr; r < r1; r += 32 * U) {
     float4 g4[U], y4[U], a4[U], d4[U];
 #pragma unroll

@@ -141,7 +141,7 @@ struct ConvParams {
   const float* bn_coef;
   float* bn_partial;
   const void* bn_a;    // that layer's activation when its ReLU mask cannot be recomputed from y (residual add) or null
-  int patch;           // 1: runs as conv_patch_kernel (conv_patch.hip; filled by plan)
+  int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel (conv_patch.hip; filled by plan)
 };
 
 struct ConvTile {
@@ -167,6 +167,7 @@ size_t conv_splitk_floats(const ConvParams& p);
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
 // conv_patch.hip: LDS-patch form of the full-resolution 16-channel 3x3 layers (chosen inside conv_igemm_plan)
 bool conv_patch_applies(const ConvParams& p, int dtype);
+bool conv_stem_applies(const ConvParams& p, int dtype);  // encoder.conv1 (7x7 stride 2, 4 staged channels)
 void conv_patch_plan(ConvParams& p);
 int conv_patch_launch(const ConvParams& p, hipStream_t stream);
 

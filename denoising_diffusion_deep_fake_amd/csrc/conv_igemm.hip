@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   const int nk_total = Kc / BKE;
   // split-K: grid.y cuts the k-tile range; each slice writes raw accumulators to its slab
-  const int kt_begin = (int)((long)nk_total * by / p.splitk);
-  const int kt_end = (int)((long)nk_total * (by + 1) / p.splitk);
+  // (wave-uniform values that come out of integer divisions live in vector registers unless told otherwise, and
+  // everything derived from them -- the whole tap walk of the main loop -- then runs on the vector ALU next to the MFMAs)
+  const int kt_begin = __builtin_amdgcn_readfirstlane((int)((long)nk_total * by / p.splitk));
+  const int kt_end = __builtin_amdgcn_readfirstlane((int)((long)nk_total * (by + 1) / p.splitk));
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
   int t_kh = 0, t_kw = 0, t_c = 0, t_seg = 0;
   if (FAST == 2) {
@@ -413,6 +415,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     t_kh = tap / KW_;
     t_kw = tap - t_kh * KW_;
   }
+  t_c = __builtin_amdgcn_readfirstlane(t_c);    // (division results: scalar registers, see kt_begin)
+  t_kh = __builtin_amdgcn_readfirstlane(t_kh);
+  t_kw = __builtin_amdgcn_readfirstlane(t_kw);
+  t_seg = __builtin_amdgcn_readfirstlane(t_seg);
 
   // Buffer descriptors (wave-uniform): lanes whose tap falls outside the image, whose row is past M
   // or whose weight row is past CoutPad get the offset BUF_OOB and read zeros in hardware -- no
@@ -703,15 +709,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ld_kwleft = kw_cur - kw0;
       if (FAST == 2) ld_segleft = nkA - kt_begin;
     }
+    if (FAST == 2) {
+      ld_seg = __builtin_amdgcn_readfirstlane(ld_seg);
+      ld_segleft = __builtin_amdgcn_readfirstlane(ld_segleft);
+    }
+    // scalar registers for the state of the tap walk (see kt_begin)
+    ld_delta = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_delta);
+    ld_bit = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_bit);
+    ld_cleft = __builtin_amdgcn_readfirstlane(ld_cleft);
+    ld_kwleft = __builtin_amdgcn_readfirstlane(ld_kwleft);
+    cpt = __builtin_amdgcn_readfirstlane(cpt);
+    rowjump = (unsigned)__builtin_amdgcn_readfirstlane((int)rowjump);
     ld_w = (unsigned)kt_begin * WSTEP;
     uint4 ra2[NVA], rb2[NVB];  // second register set
+    // Per TAP (not per k-tile): each gathered row's byte offset, or BUF_OOB when the tap misses the image -- the
+    // scalar ld_delta (< 2 GiB) added per k-tile leaves bit 31 set.  A k-tile then costs ONE vector add per gathered
+    // vector; the shift / test / select that picks the offset runs once per tap behind a wave-uniform branch.
+    unsigned tapbase[NVA];
+    auto tap_refresh = [&]() {
+#pragma unroll
+      for (int q = 0; q < NVA; ++q) {
+        if constexpr (FAST == 2) {
+          const unsigned vm = ld_seg ? vmaskB[q] : vmask[q], ro = ld_seg ? rowoffB[q] : rowoff[q];
+          tapbase[q] = ((vm >> ld_bit) & 1u) ? ro : BUF_OOB;
+        } else {
+          tapbase[q] = ((vmask[q] >> ld_bit) & 1u) ? rowoff[q] : BUF_OOB;
+        }
+      }
+    };
     auto issue_piece = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB], auto qc) {
       constexpr int q = decltype(qc)::value;
       if constexpr (q < NVA && FAST == 2) {
-        const unsigned vm = ld_seg ? vmaskB[q] : vmask[q], ro = ld_seg ? rowoffB[q] : rowoff[q];
-        A[q] = buf_load16(ld_seg ? r1 : r0, ((vm >> ld_bit) & 1u) ? ro + ld_delta : BUF_OOB);
+        A[q] = buf_load16(ld_seg ? r1 : r0, tapbase[q] + ld_delta);
       } else if constexpr (q < NVA) {
-        A[q] = buf_load16(r0, ((vmask[q] >> ld_bit) & 1u) ? rowoff[q] + ld_delta : BUF_OOB);
+        A[q] = buf_load16(r0, tapbase[q] + ld_delta);
       } else {
         Bv[q - NVA] = buf_load16(rw, woff[q - NVA] + ld_w);  // an OOB row keeps bit 31 set
       }
@@ -726,6 +757,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int rowwrap = (ld_kwleft == 0) ? 1 : 0;
       ld_kwleft = rowwrap ? kw_cur : ld_kwleft;
       ld_delta += rowwrap ? rowjump : 0u;
+      int newtap = tapwrap;
       if constexpr (FAST == 2) {  // end of segment A: restart the tap walk on the skip tensor
         const int sw = (--ld_segleft == 0) ? 1 : 0;
         ld_seg |= sw;
@@ -736,6 +768,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         ld_bit = sw ? 0u : ld_bit;
         ld_cleft = sw ? cptB : ld_cleft;
         ld_kwleft = sw ? 3 : ld_kwleft;
+        newtap |= sw;
+      }
+      if (newtap) {                // wave-uniform; the empty asm keeps it a branch (not selects on every k-tile)
+        asm volatile("" ::: "memory");
+        tap_refresh();
       }
     };
     auto issue_all = [&](uint4 (&A)[NVA], uint4 (&Bv)[NVB]) {
@@ -787,6 +824,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       advance();
     };
     const int n = kt_end - kt_begin;
+    tap_refresh();
     // prologue: tiles 0, 1 in flight; tile 0 staged; tile 2 in flight in the freed set
     issue_all(ra, rb);
     if (n > 1) issue_all(ra2, rb2);
@@ -1292,7 +1330,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
   p.patch = 0;
-  if (conv_patch_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
+  if (conv_patch_applies(p, dtype) || conv_stem_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
     conv_patch_plan(p);
     return 0;
   }

@@ -262,8 +262,183 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// encoder.conv1 (7x7, stride 2, pad 3, 3 input channels padded to 4, 64 filters) the same way.  As an implicit GEMM it
+// has 7 k-tiles, so the prologue, the per-lane tap decode of the small-channel loader and the epilogue of its 2048
+// workgroups were most of its 162 us.  Here a workgroup computes an 8 x 32 pixel output tile for 32 filters:
+//   patch: 21 x 69 input pixels x 4 channels (23 KB), columns de-interleaved (even | odd) so that the stride-2 reads
+//     of 32 consecutive output pixels are 32 consecutive 16-byte chunks (conflict-free);
+//   weights: [32][7 rows][4 tap pairs][2][4 ch] (+4 dwords per filter: conflict-free), the 8th tap of a row is zero;
+//   k-loop: v_mfma_f32_32x32x2_f32 contracts (tap 2j, tap 2j+1) x one channel per instruction -- the lane's k index
+//     selects the tap of the pair -- and skips the zero pad channel: 28 x 3 instructions per 32 x 32 fragment
+//     (168 k against the implicit GEMM's 224).
+// wave w = output rows 2w, 2w+1 of the tile; 53 KB of LDS -> 3 workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ST_PH = 8, ST_PW = 32, ST_BN = 32;
+
+bool conv_stem_applies(const ConvParams& p, int dtype) {
+  static const bool off = getenv("D3F_NO_PATCH_CONV") != nullptr;
+  if (off || dtype != D3F_F32) return false;
+  const bool mode_ok = (p.mode == CONV_RAW_STATS) || (p.mode == CONV_EVAL_FUSED && p.res == nullptr);
+  return mode_ok && p.par == 0 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.C0 == 4 && p.C1 == 0 &&
+         p.shift0 == 0 && p.zi == 0 && (p.Cout % ST_BN) == 0 && p.Hv == 2 * p.Ho && p.Wv == 2 * p.Wo &&
+         (p.Ho % ST_PH) == 0 && (p.Wo % ST_PW) == 0 && p.Kpad >= 49 * 4;
+}
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
+  constexpr int PH = ST_PH, PW = ST_PW, BN = ST_BN;
+  constexpr int PR = 2 * PH + 5, PC = 2 * PW + 5;  // 21 x 69 input pixels
+  constexpr int NE = (PC + 1) / 2;                 // even columns come first in a staged row
+  constexpr int PATCH_DW = PR * PC * 4 + 4;        // + one zeroed pixel: the pad tap of the last row reads it
+  constexpr int WS = 7 * 4 * 2 * 4 + 4;            // dwords per staged filter
+  constexpr int NPV = PR * PC, NWV = BN * 56;
+  constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
+  constexpr int BM = PH * PW, LDC = BN + 4;
+  static_assert(BM * LDC <= PATCH_DW + BN * WS, "the C tile aliases the staging area");
+  __shared__ __attribute__((aligned(16))) float lds[PATCH_DW + BN * WS];
+  float* P = lds;
+  float* Wl = lds + PATCH_DW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = p.Wo / PW, tiles_y = p.Ho / PH;
+  const int tile = (int)blockIdx.x, n0 = (int)blockIdx.y * BN;
+  const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+  const int y0 = ty * PH, x0 = tx * PW;
+
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.src0, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+  uint4 pv[NLP], wv[NLW];
+#pragma unroll
+  for (int i = 0; i < NLP; ++i) {
+    const int id = tid + 256 * i;
+    const int pr = id / PC, pc = id - pr * PC;
+    const int gy = 2 * y0 - 3 + pr, gx = 2 * x0 - 3 + pc;
+    const bool ok = id < NPV && (unsigned)gy < (unsigned)p.Hv && (unsigned)gx < (unsigned)p.Wv;
+    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * p.Hv + gy) * p.Wv + gx) * 4) * 4u : BUF_OOB);
+  }
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    const int id = tid + 256 * i;  // (filter, row kh, pair j, half h): tap kw = 2j + h
+    const int n = id / 56, r = id - n * 56, kh = r >> 3, kw = r & 7;
+    const bool ok = id < NWV && kw < 7 && (n0 + n) < p.CoutPad;
+    wv[i] = buf_load16(rw, ok ? (unsigned)((n0 + n) * p.w_ld + (kh * 7 + kw) * 4) * 4u : BUF_OOB);
+  }
+#pragma unroll
+  for (int i = 0; i < NLP; ++i) {
+    const int id = tid + 256 * i;
+    const int pr = id / PC, pc = id - pr * PC;
+    if (id < NPV) *reinterpret_cast<uint4*>(&P[(pr * PC + (pc & 1) * NE + (pc >> 1)) * 4]) = pv[i];
+  }
+  if (tid == 0) *reinterpret_cast<uint4*>(&P[PR * PC * 4]) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    const int id = tid + 256 * i;
+    const int n = id / 56, r = id - n * 56;
+    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[n * WS + r * 4]) = wv[i];
+  }
+  __syncthreads();
+
+  // lane: output pixel fr of its fragment, k index fq = which tap of the pair
+  const int fr = lane & 31, fq = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // fragment i = tile row 2*wave + i; tap (kh, kw): input row 2*(2*wave + i) + kh, column 2*fr + kw -> staged column
+  // (kw & 1) * NE + fr + (kw >> 1).  kw = 2j + fq: parity fq, offset j.
+  const float* Abase = P + ((4 * wave) * PC + fq * NE + fr) * 4;
+  const float* Bbase = Wl + fr * WS + fq * 4;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 bb = *reinterpret_cast<const uint4*>(Bbase + (kh * 4 + j) * 8);
+      uint4 a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const uint4*>(Abase + ((2 * i + kh) * PC + j) * 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i].x), __uint_as_float(bb.x), acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i].y), __uint_as_float(bb.y), acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i].z), __uint_as_float(bb.z), acc[i], 0, 0, 0);
+    }
+  }
+
+  // epilogue: register r of fragment i = out[pixel (y0 + 2*wave + i, x0 + (r&3) + 8*(r>>2) + 4*fq)][n0 + fr]
+  __syncthreads();
+  float* Cs = lds;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Cs[((2 * wave + i) * PW + (r & 3) + 8 * (r >> 2) + 4 * fq) * LDC + fr] = acc[i][r];
+  __syncthreads();
+
+  constexpr int VN = BN / 4, NVEC = BM * VN / 256, RSTEP = 256 / VN;
+  const int cv = tid % VN, rv0 = tid / VN;
+  const int n = n0 + cv * 4;
+  const long mrow0 = ((long)b * p.Ho + y0) * p.Wo + x0;
+  auto out_row = [&](int row) { return mrow0 + (long)(row / PW) * p.Wo + (row % PW); };
+  float* __restrict__ out = reinterpret_cast<float*>(p.out0);
+  if (p.mode == CONV_RAW_STATS) {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP;
+      *reinterpret_cast<float4*>(out + out_row(row) * p.Cout + n) = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+    }
+    if (p.stats != nullptr) {
+      constexpr int NG = 256 / BN;
+      const int col = tid % BN, rg = tid / BN;
+      float s1 = 0.f, s2 = 0.f;
+      for (int row = rg; row < BM; row += NG) {
+        const float v = Cs[row * LDC + col];
+        s1 += v;
+        s2 += v * v;
+      }
+      __syncthreads();
+      float* red = lds;
+      red[(rg * BN + col) * 2 + 0] = s1;
+      red[(rg * BN + col) * 2 + 1] = s2;
+      __syncthreads();
+      if (tid < BN) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          a1 += red[(g * BN + tid) * 2 + 0];
+          a2 += red[(g * BN + tid) * 2 + 1];
+        }
+        p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 0] = a1;
+        p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 1] = a2;
+      }
+    }
+  } else {  // CONV_EVAL_FUSED: folded BatchNorm (+ ReLU)
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP;
+      float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+      v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(out + out_row(row) * p.Cout + n) = v;
+    }
+  }
+}
+
 // plan: one workgroup per 4 x 64 output tile, one statistics row per tile
 void conv_patch_plan(ConvParams& p) {
+  if (p.KH == 7) {  // encoder.conv1 form: 8 x 32 tiles, 32 filters per workgroup
+    p.patch = 2;
+    p.nz = 1;
+    p.splitk = 1;
+    p.xcd_swizzle = 0;
+    p.w_ld = p.Kpad;
+    p.tiles_m = p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW);
+    p.tiles_n = p.Cout / ST_BN;
+    p.stat_rows = p.tiles_m;
+    return;
+  }
   p.patch = 1;
   p.nz = 1;
   p.splitk = 1;
@@ -275,6 +450,13 @@ void conv_patch_plan(ConvParams& p) {
 }
 
 int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
+  if (p.patch == 2) {
+    D3F_CHECK(p.tiles_m == p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW) && p.tiles_n == p.Cout / ST_BN && p.C0 == 4,
+              "conv: stem patch params were not planned");
+    hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
+    D3F_HIP(hipGetLastError());
+    return 0;
+  }
   D3F_CHECK(p.patch == 1 && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) && p.C0 == 16 && p.Cout <= 16,
             "conv: patch params were not planned");
   hipLaunchKernelGGL((conv_patch_kernel<16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);

@@ -131,6 +131,9 @@ def test_conv_f32x3_first_layer_and_large_tiles(ops):
 def test_conv_first_layer_7x7(ops):
     # encoder.conv1: 3 real input channels padded to 4, 7x7 stride 2
     _conv_case(ops, 2, 32, 32, 4, 0, 64, 7, 2, 3, False, cin_real=3)
+    # wide enough for conv_stem_kernel (8 x 32 output tiles): image borders on all four sides of one / several tiles
+    _conv_case(ops, 2, 32, 64, 4, 0, 64, 7, 2, 3, False, cin_real=3, seed=2)
+    _conv_case(ops, 1, 48, 128, 4, 0, 64, 7, 2, 3, False, cin_real=3, seed=3)
 
 
 def test_conv_large_tiles(ops):
