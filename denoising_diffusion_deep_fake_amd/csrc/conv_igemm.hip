@@ -997,40 +997,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  if (p.mode == CONV_RAW_STATS) {
-    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
+  constexpr int EPU = NVEC > 8 ? 4 : NVEC;  // unroll bound of the epilogue loops (128x128: 16 vectors per thread)
+  // Column sums for the statistics epilogues: every thread already holds its NVEC rows x 4 columns of the tile in
+  // registers for the store, so it sums those, and the 256 / VN thread rows are added through LDS in thread-row order
+  // (fixed order: reproducible).  red = [RSTEP][BN][2] floats = 8 KB, in the C tile's space.
+  auto column_totals = [&](const float (&s1)[4], const float (&s2)[4], float& a1, float& a2) {
+    __syncthreads();  // all reads of the C tile are done
+    float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
-    for (int i = 0; i < NVEC; ++i) {
-      const int row = rv0 + i * RSTEP, m = m0 + row;
-      if (n_ok && m < p.M) {
-        const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
-        store4(out + orow * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
+    for (int k = 0; k < 4; ++k) {
+      red[((rv0 * BN) + cv * 4 + k) * 2 + 0] = s1[k];
+      red[((rv0 * BN) + cv * 4 + k) * 2 + 1] = s2[k];
+    }
+    __syncthreads();
+    a1 = a2 = 0.f;
+    if (tid < BN) {
+#pragma unroll 8
+      for (int g = 0; g < RSTEP; ++g) {
+        a1 += red[(g * BN + tid) * 2 + 0];
+        a2 += red[(g * BN + tid) * 2 + 1];
       }
     }
-    if (p.stats != nullptr) {
-      // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
-      constexpr int NG = 256 / BN;  // row groups
-      const int col = tid % BN, rg = tid / BN;
-      float s1 = 0.f, s2 = 0.f;
-      for (int row = rg; row < BM; row += NG) {
-        const float v = Cs[row * LDC + col];
-        s1 += v;
-        s2 += v * v;
-      }
-      __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
-      float* red = reinterpret_cast<float*>(lds);
-      red[(rg * BN + col) * 2 + 0] = s1;
-      red[(rg * BN + col) * 2 + 1] = s2;
-      __syncthreads();
-      if (tid < BN) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          a1 += red[(g * BN + tid) * 2 + 0];
-          a2 += red[(g * BN + tid) * 2 + 1];
+  };
+
+  if (p.mode == CONV_RAW_STATS) {
+    if constexpr (NVEC > 8 || BM == 256) {  // 128x128 and 256-row tiles: the scalar column loop (the vector form costs them a wave per SIMD)
+      T* __restrict__ out = reinterpret_cast<T*>(p.out0);
+  #pragma unroll
+      for (int i = 0; i < NVEC; ++i) {
+        const int row = rv0 + i * RSTEP, m = m0 + row;
+        if (n_ok && m < p.M) {
+          const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
+          store4(out + orow * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
         }
+      }
+      if (p.stats != nullptr) {
+        // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
+        constexpr int NG = 256 / BN;  // row groups
+        const int col = tid % BN, rg = tid / BN;
+        float s1 = 0.f, s2 = 0.f;
+        for (int row = rg; row < BM; row += NG) {
+          const float v = Cs[row * LDC + col];
+          s1 += v;
+          s2 += v * v;
+        }
+        __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
+        float* red = reinterpret_cast<float*>(lds);
+        red[(rg * BN + col) * 2 + 0] = s1;
+        red[(rg * BN + col) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < BN) {
+          float a1 = 0.f, a2 = 0.f;
+  #pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            a1 += red[(g * BN + tid) * 2 + 0];
+            a2 += red[(g * BN + tid) * 2 + 1];
+          }
+          const int nn = n0 + tid;
+          if (nn < p.CoutPad) {
+            const long st = (long)bz * p.tiles_m + tile_m;  // one partial row per (class, m-tile)
+            p.stats[(st * p.CoutPad + nn) * 2 + 0] = a1;
+            p.stats[(st * p.CoutPad + nn) * 2 + 1] = a2;
+          }
+        }
+      }
+    } else {
+      T* __restrict__ out = reinterpret_cast<T*>(p.out0);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll EPU
+      for (int i = 0; i < NVEC; ++i) {
+        const int row = rv0 + i * RSTEP, m = m0 + row;
+        const float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+        if (n_ok && m < p.M) {
+          const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
+          store4(out + orow * p.Cout + n, v);
+        }
+        // rows beyond M were gathered as zeros (no bias) -> contribute 0 to both sums
+        s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+        s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
+      }
+      if (p.stats != nullptr) {
+        float a1, a2;
+        column_totals(s1, s2, a1, a2);
         const int nn = n0 + tid;
-        if (nn < p.CoutPad) {
+        if (tid < BN && nn < p.CoutPad) {
           const long st = (long)bz * p.tiles_m + tile_m;  // one partial row per (class, m-tile)
           p.stats[(st * p.CoutPad + nn) * 2 + 0] = a1;
           p.stats[(st * p.CoutPad + nn) * 2 + 1] = a2;
@@ -1042,7 +1092,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
     if (n_ok) {
       const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
-#pragma unroll
+#pragma unroll EPU
       for (int i = 0; i < NVEC; ++i) {
         const int row = rv0 + i * RSTEP, m = m0 + row;
         if (m >= p.M) continue;
@@ -1058,67 +1108,147 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }
     }
   } else if (p.mode == CONV_DGRAD) {
-    T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
-    T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
-    if (n_ok) {
-      const bool first = n < p.out_c0;  // out_c0 is a multiple of 4 (plan)
-      T* __restrict__ base = first ? o0 + n : o1 + (n - p.out_c0);
-      const int ld = first ? p.out_c0 : p.Cout - p.out_c0;
-      const bool accum = first ? p.acc0 : p.acc1;
-#pragma unroll
-      for (int i = 0; i < NVEC; ++i) {
-        const int row = rv0 + i * RSTEP, m = m0 + row;
-        if (m >= p.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
-        const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
-        T* dst = base + orow * ld;
-        if (accum) {
-          const float4 o = load4(dst);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-          // a fused BatchNorm reduction (below) works on the FINAL gradient: this launch is its last writer
-          if (p.bn_partial != nullptr) *reinterpret_cast<float4*>(&Cs[row * LDC + cv * 4]) = v;
-        }
-        store4(dst, v);
-      }
-    }
-    if (p.bn_partial != nullptr) {
-      // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, this launch is the last
-      // writer of the gradient): column sums over this tile's rows of dz and dz * xhat.  ReLU mask: recomputed from
-      // y by the forward's own arithmetic, or -- layers with a residual, bn_a != null -- read from the activation
-      if (p.acc0) __syncthreads();  // the accumulated values above were written back to the C tile
-      constexpr int NG = 256 / BN;
-      const int col = tid % BN, rg = tid / BN;
-      const int nn = n0 + col, C = p.Cout;
-      const bool cok = nn < C;
-      const float mu = cok ? p.bn_coef[nn] : 0.f, is = cok ? p.bn_coef[C + nn] : 0.f;
-      const float sc = cok ? p.bn_coef[2 * C + nn] : 0.f, sf = cok ? p.bn_coef[3 * C + nn] : 0.f;
-      const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
-      const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
-      float s1 = 0.f, s2 = 0.f;
-      for (int row = rg; row < BM; row += NG) {
-        const int m = m0 + row;
-        if (cok && m < p.M) {
-          const float yy = to_f32<T>(yb[(long)m * C + nn]);
-          const float keep = ab != nullptr ? to_f32<T>(ab[(long)m * C + nn]) : yy * sc + sf;
-          const float g = keep > 0.f ? Cs[row * LDC + col] : 0.f;
-          s1 += g;
-          s2 += g * ((yy - mu) * is);
+    if constexpr (NVEC > 8 || BM == 256) {
+      T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
+      T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
+      if (n_ok) {
+        const bool first = n < p.out_c0;  // out_c0 is a multiple of 4 (plan)
+        T* __restrict__ base = first ? o0 + n : o1 + (n - p.out_c0);
+        const int ld = first ? p.out_c0 : p.Cout - p.out_c0;
+        const bool accum = first ? p.acc0 : p.acc1;
+  #pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+          const int row = rv0 + i * RSTEP, m = m0 + row;
+          if (m >= p.M) continue;
+          float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+          const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
+          T* dst = base + orow * ld;
+          if (accum) {
+            const float4 o = load4(dst);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            // a fused BatchNorm reduction (below) works on the FINAL gradient: this launch is its last writer
+            if (p.bn_partial != nullptr) *reinterpret_cast<float4*>(&Cs[row * LDC + cv * 4]) = v;
+          }
+          store4(dst, v);
         }
       }
-      __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
-      float* red = reinterpret_cast<float*>(lds);
-      red[(rg * BN + col) * 2 + 0] = s1;
-      red[(rg * BN + col) * 2 + 1] = s2;
-      __syncthreads();
-      if (tid < BN) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          a1 += red[(g * BN + tid) * 2 + 0];
-          a2 += red[(g * BN + tid) * 2 + 1];
+      if (p.bn_partial != nullptr) {
+        // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, this launch is the last
+        // writer of the gradient): column sums over this tile's rows of dz and dz * xhat.  ReLU mask: recomputed from
+        // y by the forward's own arithmetic, or -- layers with a residual, bn_a != null -- read from the activation
+        if (p.acc0) __syncthreads();  // the accumulated values above were written back to the C tile
+        constexpr int NG = 256 / BN;
+        const int col = tid % BN, rg = tid / BN;
+        const int nn = n0 + col, C = p.Cout;
+        const bool cok = nn < C;
+        const float mu = cok ? p.bn_coef[nn] : 0.f, is = cok ? p.bn_coef[C + nn] : 0.f;
+        const float sc = cok ? p.bn_coef[2 * C + nn] : 0.f, sf = cok ? p.bn_coef[3 * C + nn] : 0.f;
+        const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+        const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
+        float s1 = 0.f, s2 = 0.f;
+        for (int row = rg; row < BM; row += NG) {
+          const int m = m0 + row;
+          if (cok && m < p.M) {
+            const float yy = to_f32<T>(yb[(long)m * C + nn]);
+            const float keep = ab != nullptr ? to_f32<T>(ab[(long)m * C + nn]) : yy * sc + sf;
+            const float g = keep > 0.f ? Cs[row * LDC + col] : 0.f;
+            s1 += g;
+            s2 += g * ((yy - mu) * is);
+          }
         }
+        __syncthreads();  // all reads of the C tile are done: reuse its space for the group partials
+        float* red = reinterpret_cast<float*>(lds);
+        red[(rg * BN + col) * 2 + 0] = s1;
+        red[(rg * BN + col) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < BN) {
+          float a1 = 0.f, a2 = 0.f;
+  #pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            a1 += red[(g * BN + tid) * 2 + 0];
+            a2 += red[(g * BN + tid) * 2 + 1];
+          }
+          const int c = n0 + tid;
+          if (c < C) {
+            p.bn_partial[((long)tile_m * C + c) * 2 + 0] = a1;
+            p.bn_partial[((long)tile_m * C + c) * 2 + 1] = a2;
+          }
+        }
+      }
+    } else {
+      T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
+      T* __restrict__ o1 = reinterpret_cast<T*>(p.out1);
+      if (n_ok) {
+        const bool first = n < p.out_c0;  // out_c0 is a multiple of 4 (plan)
+        T* __restrict__ base = first ? o0 + n : o1 + (n - p.out_c0);
+        const int ld = first ? p.out_c0 : p.Cout - p.out_c0;
+        const bool accum = first ? p.acc0 : p.acc1;
+  #pragma unroll EPU
+        for (int i = 0; i < NVEC; ++i) {
+          const int row = rv0 + i * RSTEP, m = m0 + row;
+          if (m >= p.M) continue;
+          float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+          const long orow = p.par ? par_out_row(p, par_py, par_px, m) : (long)m;
+          T* dst = base + orow * ld;
+          if (accum) {
+            const float4 o = load4(dst);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            // a fused BatchNorm reduction (below) works on the FINAL gradient: this launch is its last writer.  The thread
+            // re-reads its own slot (no barrier needed).
+            if (p.bn_partial != nullptr) *reinterpret_cast<float4*>(&Cs[row * LDC + cv * 4]) = v;
+          }
+          store4(dst, v);
+        }
+      }
+      if (p.bn_partial != nullptr) {
+        // fused BatchNorm-backward reduction of the consuming layer (plan: single destination, no parity classes, this
+        // launch is the last writer of the gradient): column sums over this tile's rows of dz and dz * xhat.  ReLU mask:
+        // recomputed from y by the forward's own arithmetic, or -- layers with a residual, bn_a != null -- read from the
+        // activation.  16-byte loads of y (and a) for the thread's own rows, all in flight together.
+        const int C = p.Cout;
+        const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+        const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok) {
+          const float4 mu = *reinterpret_cast<const float4*>(p.bn_coef + n), is = *reinterpret_cast<const float4*>(p.bn_coef + C + n);
+          const float4 sc = *reinterpret_cast<const float4*>(p.bn_coef + 2 * C + n), sf = *reinterpret_cast<const float4*>(p.bn_coef + 3 * C + n);
+          const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+          const float c4[4] = {sc.x, sc.y, sc.z, sc.w}, f4[4] = {sf.x, sf.y, sf.z, sf.w};
+          constexpr int HB = NVEC < 4 ? NVEC : 4;  // rows in flight per batch (bounds the registers of the epilogue)
+  #pragma unroll 2
+          for (int i0 = 0; i0 < NVEC; i0 += HB) {
+            float4 yv[HB], av[HB];
+  #pragma unroll
+            for (int j = 0; j < HB; ++j) {
+              const int m = m0 + rv0 + (i0 + j) * RSTEP;
+              yv[j] = av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (m < p.M) {
+                yv[j] = load4(yb + (long)m * C + n);
+                if (ab != nullptr) av[j] = load4(ab + (long)m * C + n);
+              }
+            }
+  #pragma unroll
+            for (int j = 0; j < HB; ++j) {
+              const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w};
+              const float aa[4] = {av[j].x, av[j].y, av[j].z, av[j].w};
+              const int row = rv0 + (i0 + j) * RSTEP;
+              const float4 gv = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+              const bool rok = m0 + row < p.M;
+              const float gg[4] = {rok ? gv.x : 0.f, rok ? gv.y : 0.f, rok ? gv.z : 0.f, rok ? gv.w : 0.f};
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float keep = ab != nullptr ? aa[k] : yy[k] * c4[k] + f4[k];
+                const float g = keep > 0.f ? gg[k] : 0.f;
+                s1[k] += g;
+                s2[k] += g * ((yy[k] - m4[k]) * i4[k]);
+              }
+            }
+          }
+        }
+        float a1, a2;
+        column_totals(s1, s2, a1, a2);
         const int c = n0 + tid;
-        if (c < C) {
+        if (tid < BN && c < C) {
           p.bn_partial[((long)tile_m * C + c) * 2 + 0] = a1;
           p.bn_partial[((long)tile_m * C + c) * 2 + 1] = a2;
         }
