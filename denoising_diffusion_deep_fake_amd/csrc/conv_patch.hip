@@ -220,36 +220,50 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
       }
     }
     if (p.bn_partial != nullptr) {
-      // fused BatchNorm-backward reduction of the consuming layer (conv_igemm.hip, same arithmetic and row order)
-      if (p.acc0) __syncthreads();
-      constexpr int NG = 256 / BN;
-      const int col = tid % BN, rg = tid / BN;
+      // fused BatchNorm-backward reduction of the consuming layer (as conv_igemm.hip): 16-byte loads of y (and a) for
+      // the thread's own rows, column sums in registers, thread rows added through LDS in order
       const int C = p.Cout;
-      const bool cok = col < C;
-      const float mu = cok ? p.bn_coef[col] : 0.f, is = cok ? p.bn_coef[C + col] : 0.f;
-      const float sc = cok ? p.bn_coef[2 * C + col] : 0.f, sf = cok ? p.bn_coef[3 * C + col] : 0.f;
       const float* __restrict__ yb = reinterpret_cast<const float*>(p.bn_y);
       const float* __restrict__ ab = reinterpret_cast<const float*>(p.bn_a);
-      float s1 = 0.f, s2 = 0.f;
-      if (cok) {
-        for (int row = rg; row < BM; row += NG) {
-          const long m = out_row(row);
-          const float yy = yb[m * C + col];
-          const float keep = ab != nullptr ? ab[m * C + col] : yy * sc + sf;
-          const float g = keep > 0.f ? Cs[row * LDC + col] : 0.f;
-          s1 += g;
-          s2 += g * ((yy - mu) * is);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n_ok) {
+        const float4 mu = *reinterpret_cast<const float4*>(p.bn_coef + n), is = *reinterpret_cast<const float4*>(p.bn_coef + C + n);
+        const float4 sc = *reinterpret_cast<const float4*>(p.bn_coef + 2 * C + n), sf = *reinterpret_cast<const float4*>(p.bn_coef + 3 * C + n);
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+        const float c4[4] = {sc.x, sc.y, sc.z, sc.w}, f4[4] = {sf.x, sf.y, sf.z, sf.w};
+        float4 yv[NVEC], av[NVEC];
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+          const long m = out_row(rv0 + i * RSTEP);
+          yv[i] = *reinterpret_cast<const float4*>(yb + m * C + n);
+          av[i] = ab != nullptr ? *reinterpret_cast<const float4*>(ab + m * C + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+          const float4 gv = *reinterpret_cast<const float4*>(&Cs[(rv0 + i * RSTEP) * LDC + cv * 4]);  // own slot
+          const float yy[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w}, aa[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+          const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float keep = ab != nullptr ? aa[k] : yy[k] * c4[k] + f4[k];
+            const float g = keep > 0.f ? gg[k] : 0.f;
+            s1[k] += g;
+            s2[k] += g * ((yy[k] - m4[k]) * i4[k]);
+          }
         }
       }
-      __syncthreads();
-      float* red = lds;
-      red[(rg * BN + col) * 2 + 0] = s1;
-      red[(rg * BN + col) * 2 + 1] = s2;
+      __syncthreads();  // all reads of the C tile are done
+      float* red = lds;  // [RSTEP][BN][2]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[(rv0 * BN + cv * 4 + k) * 2 + 0] = s1[k];
+        red[(rv0 * BN + cv * 4 + k) * 2 + 1] = s2[k];
+      }
       __syncthreads();
       if (tid < BN) {
         float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
+#pragma unroll 8
+        for (int g = 0; g < RSTEP; ++g) {
           a1 += red[(g * BN + tid) * 2 + 0];
           a2 += red[(g * BN + tid) * 2 + 1];
         }
