@@ -27,7 +27,8 @@ constexpr int BNF_MAX_ROWS = 512;
 
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   static const bool off = getenv("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
-  return !off && dtype == D3F_F32 && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= BNF_MAX_ROWS;
+  static const int max_rows = getenv("D3F_BN_FUSED_MAX_ROWS") ? atoi(getenv("D3F_BN_FUSED_MAX_ROWS")) : BNF_MAX_ROWS;  // tuning knob
+  return !off && dtype == D3F_F32 && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= max_rows;
 }
 
 // sums the partial rows [rows][ld][2] of channels [c0, c0 + 32) in f64: thread (rl = tid / 16, q = tid % 16) owns the

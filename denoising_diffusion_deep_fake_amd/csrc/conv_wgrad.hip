@@ -466,7 +466,7 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   p.tiles_ci = cdiv(cin, t.bn);
   const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW * group;
   const int total_chunks = cdiv(p.M, KP);
-  long target = 1024;  // aim at ~4 blocks per CU
+  long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
   if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
   long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab

@@ -6,6 +6,7 @@
 // Python side can expose ordinary nn.Parameters that are views into one flat buffer and keep
 // smp-compatible state_dict keys.
 #include "engine.h"
+#include <vector>
 
 #include <cstdio>
 #include <cstdlib>
@@ -848,8 +849,55 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   float* wpart = reinterpret_cast<float*>(ws + wpart_off);
   size_t next_event = 0;
   bool side_used = false;
+  // Weight-gradient launches waiting for their "dY ready" event.  One event per launch by default; tuning knob
+  // D3F_WGRAD_DEFER=n records one event for every n launches (an event record costs the chain a few us of dispatch
+  // latency, a deferred launch starts later).  Pending launches never cross a gradient-bucket (segment) boundary.
+  static const int defer = getenv("D3F_WGRAD_DEFER") ? std::max(1, atoi(getenv("D3F_WGRAD_DEFER"))) : 1;
+  std::vector<int> pending;
+  int pending_segment = -1;
+  auto flush_pending = [&]() -> int {
+    if (pending.empty()) return 0;
+    if (!serial) {
+      if (next_event == ev_dy_.size()) {
+        hipEvent_t e = nullptr;
+        D3F_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev_dy_.push_back(e);
+      }
+      D3F_HIP(hipEventRecord(ev_dy_[next_event], s));
+      D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[next_event], 0));
+      ++next_event;
+      side_used = true;
+    }
+    for (int ui : pending) {
+      const Unit& u = units[ui];
+      const WGroup& grp = wgroups[u.wgroup];
+      WgradParams g = grp.wg;
+      WgradGroup gp;
+      WgradDst gd;
+      gp.n = gd.n = (int)grp.units.size();
+      for (int i = 0; i < gp.n; ++i) {
+        const Unit& m = units[grp.units[i]];
+        gp.dy[i] = ws + m.dy_off;
+        gp.src0[i] = T(m.in0);
+        gd.dw[i] = grads + m.w_off;
+      }
+      g.dy = gp.dy[0];
+      g.src0 = gp.src0[0];
+      g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;  // two-source layers are never grouped
+      g.partial = wpart;
+      if (int rc = wgrad_launch_group(g, gp, cdtype, ws_stream)) return rc;
+      if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
+        return rc;
+    }
+    pending.clear();
+    return 0;
+  };
   for (const BwdOp& op : bwd_ops) {
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
+    if (op.segment != pending_segment) {
+      if (int rc = flush_pending()) return rc;
+      pending_segment = op.segment;
+    }
     if (aux_used && !aux_joined && op.segment != 0) {
       // leaving the decoder bucket: the encoder stages read and accumulate into the skip tensors' gradients
       D3F_HIP(hipEventRecord(ev_aux_, aux_));
@@ -915,34 +963,9 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     // weight gradient of the unit's launch group (side stream), once the group's last dY exists
     const WGroup& grp = wgroups[u.wgroup];
     if (grp.units.back() == op.unit && !skip_w) {
-      if (!serial) {
-        if (next_event == ev_dy_.size()) {
-          hipEvent_t e = nullptr;
-          D3F_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          ev_dy_.push_back(e);
-        }
-        D3F_HIP(hipEventRecord(ev_dy_[next_event], s));
-        D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[next_event], 0));
-        ++next_event;
-        side_used = true;
-      }
-      WgradParams g = grp.wg;
-      WgradGroup gp;
-      WgradDst gd;
-      gp.n = gd.n = (int)grp.units.size();
-      for (int i = 0; i < gp.n; ++i) {
-        const Unit& m = units[grp.units[i]];
-        gp.dy[i] = ws + m.dy_off;
-        gp.src0[i] = T(m.in0);
-        gd.dw[i] = grads + m.w_off;
-      }
-      g.dy = gp.dy[0];
-      g.src0 = gp.src0[0];
-      g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;  // two-source layers are never grouped
-      g.partial = wpart;
-      if (int rc = wgrad_launch_group(g, gp, cdtype, ws_stream)) return rc;
-      if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
-        return rc;
+      pending.push_back(op.unit);
+      if ((int)pending.size() >= defer)
+        if (int rc = flush_pending()) return rc;
     }
     // data gradient (main stream)
     if (u.need_dgrad && !skip_d && u.upfold) {
@@ -1013,6 +1036,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
     }
   }
+  if (int rc = flush_pending()) return rc;
   if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream
     D3F_HIP(hipEventRecord(ev_join_, side_));
     D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
