@@ -849,10 +849,12 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   float* wpart = reinterpret_cast<float*>(ws + wpart_off);
   size_t next_event = 0;
   bool side_used = false;
-  // Weight-gradient launches waiting for their "dY ready" event.  One event per launch by default; tuning knob
-  // D3F_WGRAD_DEFER=n records one event for every n launches (an event record costs the chain a few us of dispatch
-  // latency, a deferred launch starts later).  Pending launches never cross a gradient-bucket (segment) boundary.
-  static const int defer = getenv("D3F_WGRAD_DEFER") ? std::max(1, atoi(getenv("D3F_WGRAD_DEFER"))) : 1;
+  // Weight-gradient launches waiting for their "dY ready" event: one event for every `defer` launches (an event
+  // record costs the chain a few us of dispatch latency, a deferred launch starts later).  Measured (r02_ap/aq,
+  // D3F_WGRAD_DEFER=1/2/3/4): 3 gives the shortest data-gradient launches (class 3.80 -> 3.64 ms per step) at an
+  // equal or slightly shorter step; 2 and 4 are 0.5-1 % slower.  Pending launches never cross a gradient-bucket
+  // (segment) boundary.
+  static const int defer = getenv("D3F_WGRAD_DEFER") ? std::max(1, atoi(getenv("D3F_WGRAD_DEFER"))) : 3;
   std::vector<int> pending;
   int pending_segment = -1;
   auto flush_pending = [&]() -> int {
