@@ -863,16 +863,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   } else
   if constexpr (!DB) {
     // single LDS stage: stage -> barrier -> (next tile's loads behind the MFMAs) -> barrier
+    // (the last tile is peeled: with "if (last) compute else compute_and_load" inside the loop the compiler copied all
+    // accumulators between AGPRs and VGPRs on every iteration -- 64 v_accvgpr moves per k-tile)
     load_tile(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; ++kt) {
       stage(0);
       __syncthreads();
-      if (kt + 1 < kt_end) {
-        const TileCtx x = tile_setup(kt + 1);
-        compute_and_load(0, x);
-      } else {
-        compute(0, no_hook);
-      }
+      const TileCtx x = tile_setup(kt + 1);
+      compute_and_load(0, x);
+      __syncthreads();
+    }
+    if (kt < kt_end) {
+      stage(0);
+      __syncthreads();
+      compute(0, no_hook);
       __syncthreads();
     }
   } else {
