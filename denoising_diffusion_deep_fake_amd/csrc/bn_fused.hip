@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 
 // rows per workgroup: ~512 workgroups in all, whole passes of 32 rows
 static long rows_per_block_for(long rows, int slabs) {
-  long rb = std::max(1L, 512L / slabs);
+  static const long wgs = getenv("D3F_BN_FUSED_WGS") ? std::max(64, atoi(getenv("D3F_BN_FUSED_WGS"))) : 512;  // tuning knob
+  long rb = std::max(1L, wgs / slabs);
   long rpb = (rows + rb - 1) / rb;
   rpb = (rpb + 31) / 32 * 32;
   return std::max(32L, rpb);
