@@ -148,9 +148,12 @@ class UnetEngine {
   // packed on the caller's stream, the rest on the side stream while those layers already run; the forward pass
   // waits for it in front of the first later layer
   int ensure_streams() const;
-  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr;
-  mutable bool pack_pending_ = false;
-  int first_late_unit_ = -1;  // first unit (index into `units`) whose packed weights come from the side stream
+  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr, ev_pack_mid_ = nullptr;
+  mutable bool pack_pending_ = false, pack_mid_pending_ = false;
+  // Weight packing in three parts: encoder.conv1 on the caller's stream (the forward needs it at once), layer1-2 and
+  // then everything else on the side stream, each behind its own event.
+  int first_mid_unit_ = -1;   // first unit (index into `units`) of the second part (encoder.layer1)
+  int first_late_unit_ = -1;  // first unit of the third part (encoder.layer3)
   mutable hipStream_t aux_ = nullptr;
   mutable hipEvent_t ev_aux_ = nullptr;
   mutable std::vector<hipEvent_t> ev_auxdy_;

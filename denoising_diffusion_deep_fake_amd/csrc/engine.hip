@@ -345,6 +345,9 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
     if (int rc = plan_unit(u)) return rc;
   for (int ui = 0; ui < (int)units.size() && first_late_unit_ < 0; ++ui)
     if (units[ui].conv_name.rfind("encoder.layer3.", 0) == 0) first_late_unit_ = ui;
+  for (int ui = 0; ui < (int)units.size() && first_mid_unit_ < 0; ++ui)
+    if (units[ui].conv_name.rfind("encoder.layer1.", 0) == 0) first_mid_unit_ = ui;
+  if (first_late_unit_ <= 0 || first_mid_unit_ <= 0 || first_mid_unit_ >= first_late_unit_) first_mid_unit_ = -1;
 
   // ---- backward schedule (static: first writer writes, later writers accumulate) --------
   auto grad_dst = [&](int tid, bool* acc) {
@@ -559,6 +562,7 @@ int UnetEngine::ensure_streams() const {
   D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_done_, hipEventDisableTiming));
+  D3F_HIP(hipEventCreateWithFlags(&ev_pack_mid_, hipEventDisableTiming));
   return 0;
 }
 
@@ -568,14 +572,20 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
   static const bool sync_pack = getenv("D3F_NO_ASYNC_PACK") != nullptr;  // debugging knob: everything on the caller's stream
   const bool async = !sync_pack && first_late_unit_ > 0;
   char* ws = reinterpret_cast<char*>(ws_);
-  for (int part = 0; part < 2; ++part) {  // 0: the first layers (caller's stream), 1: the rest
+  static const bool no_mid = getenv("D3F_NO_PACK_MID") != nullptr;  // debugging knob: two parts (layer1-2 with conv1)
+  const int mid = (async && !no_mid) ? first_mid_unit_ : -1;
+  // parts: 0 = the first layers (caller's stream: encoder.conv1, or everything before layer3 without a middle part),
+  // 1 = layer1-2 (side stream, own event; empty without a middle part), 2 = the rest (side stream)
+  auto part_of = [&](int ui) { return ui >= first_late_unit_ ? 2 : (mid > 0 && ui >= mid) ? 1 : 0; };
+  for (int part = 0; part < 3; ++part) {
+    if (part == 1 && mid <= 0) continue;
     PackTable t;
     t.n = 0;
     uint32_t blocks = 0;
     for (int ui = 0; ui < (int)units.size(); ++ui) {
       const Unit& u = units[ui];
-      if ((ui >= first_late_unit_ ? 1 : 0) != part && first_late_unit_ > 0) continue;
-      if (first_late_unit_ <= 0 && part == 1) continue;
+      if (first_late_unit_ > 0 && part_of(ui) != part) continue;
+      if (first_late_unit_ <= 0 && part != 0) continue;
       if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
       PackEntry& e = t.e[t.n++];
       const int CoutD = (int)round_up(u.Cout, ve);
@@ -605,14 +615,21 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
     }
     hipStream_t ps = s;
-    if (part == 1 && async) {
+    if (part >= 1 && async) {
       if (int rc = ensure_streams()) return rc;
-      D3F_HIP(hipEventRecord(ev_pack_in_, s));  // the parameter update (and every reader of the old layouts) is done
-      D3F_HIP(hipStreamWaitEvent(side_, ev_pack_in_, 0));
+      if (part == 1 || mid <= 0) {
+        D3F_HIP(hipEventRecord(ev_pack_in_, s));  // the parameter update (and every reader of the old layouts) is done
+        D3F_HIP(hipStreamWaitEvent(side_, ev_pack_in_, 0));
+      }
       ps = side_;
     }
-    if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
-    if (part == 1 || first_late_unit_ <= 0) {
+    if (t.n > 0)
+      if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
+    if (part == 1 && async) {
+      D3F_HIP(hipEventRecord(ev_pack_mid_, side_));
+      pack_mid_pending_ = true;
+    }
+    if (part == 2 || first_late_unit_ <= 0) {
       for (const Unit& u : units)  // the folded decoder layers: all late
         if (u.upfold)
           if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
@@ -620,7 +637,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
                                       (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, ps))
             return rc;
     }
-    if (part == 1 && async) {
+    if (part == 2 && async) {
       D3F_HIP(hipEventRecord(ev_pack_done_, side_));
       pack_pending_ = true;
     }
@@ -668,6 +685,10 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       continue;
     }
     const Unit& u = units[ui];
+    if (pack_mid_pending_ && ui >= first_mid_unit_) {  // layer1-2: second part
+      D3F_HIP(hipStreamWaitEvent(s, ev_pack_mid_, 0));
+      pack_mid_pending_ = false;
+    }
     if (pack_pending_ && ui >= first_late_unit_) {  // packed weights of the later layers come from the side stream
       D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
       pack_pending_ = false;
@@ -756,7 +777,11 @@ int UnetEngine::predict_u8(const float* params_, float* bnstats, const uint8_t* 
     s255[c] = stdv[c] * 255.0f;
   }
   if (!use_graph) return predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, s);
-  if (pack_pending_) {  // not inside the capture: the replay stream is ordered after the caller's stream below
+  if (pack_mid_pending_) {  // not inside the capture: the replay stream is ordered after the caller's stream below
+    D3F_HIP(hipStreamWaitEvent(s, ev_pack_mid_, 0));
+    pack_mid_pending_ = false;
+  }
+  if (pack_pending_) {
     D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
     pack_pending_ = false;
   }
@@ -812,6 +837,7 @@ UnetEngine::~UnetEngine() {
   if (ev_aux_) (void)hipEventDestroy(ev_aux_);
   if (ev_pack_in_) (void)hipEventDestroy(ev_pack_in_);
   if (ev_pack_done_) (void)hipEventDestroy(ev_pack_done_);
+  if (ev_pack_mid_) (void)hipEventDestroy(ev_pack_mid_);
   if (aux_) (void)hipStreamDestroy(aux_);
   if (side_) (void)hipStreamDestroy(side_);
 }
