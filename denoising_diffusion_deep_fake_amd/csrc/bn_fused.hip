@@ -4,8 +4,8 @@
 // bn_apply (streaming pass), and backward as   partial sums (data-gradient epilogue) -> bn_bwd_finalize ->
 // bn_bwd_apply.  On the training step's critical path every one of those 92 finalize launches costs its dispatch
 // latency plus 5-14 us of a kernel that keeps 64-512 workgroups busy for a few hundred loads each.  Here the streaming
-// kernel's workgroups REDUNDANTLY reduce the partial rows of their own 32-channel slab first (f64, fixed order, 8-128
-// KB of L2-resident partials per workgroup, 512 KB for the stem), derive the slab's coefficients in LDS and go straight on to the
+// kernel's workgroups REDUNDANTLY reduce the partial rows of their own 32-channel slab first (f64, fixed order, 8-256
+// KB of L2-resident partials per workgroup), derive the slab's coefficients in LDS and go straight on to the
 // streaming pass: no second launch, no atomics, no fences, and every workgroup computes bit-identical coefficients.
 // Row block 0 of each slab also writes the coefficients (the backward pass and the data-gradient epilogues read them)
 // and updates the running statistics / dgamma, dbeta.  Replaces ATen's batch_norm / batch_norm_backward under
@@ -20,7 +20,7 @@
 namespace d3f {
 
 constexpr int BNF_SC = 32;         // channels per slab = one 128-byte line per tensor row
-constexpr int BNF_MAX_ROWS = 2048;  // partial rows a workgroup is asked to reduce (x 256 B); 512: +0.3 % step, 4096: equal
+constexpr int BNF_MAX_ROWS = 1024;  // partial rows a workgroup is asked to reduce (x 256 B): 512 / 1024 / 2048 within 0.2 % of each other; 2048 would take in the stem, whose 512 KB prologue per workgroup makes the pass 3x longer
 #ifndef BNF_BWD_U
 #define BNF_BWD_U 2  // rows in flight per thread in the backward streaming pass (4: +0.4 % step time -- 142 VGPRs leave one workgroup per CU next to the weight-gradient stream)
 #endif  // partial rows a workgroup is asked to reduce (x 256 B)
