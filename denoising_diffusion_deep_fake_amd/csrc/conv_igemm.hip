@@ -849,15 +849,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
       }
     }
-    for (; t < n; ++t) {             // tail (at most 4 tiles): same schedule with bounds checks
-      const int cur = t & 1;
-      if (t + 1 < n) {
-        if (cur == 0) stage_set(1, ra2, rb2); else stage_set(0, ra, rb);
-      }
-      if (t + 3 < n) {
-        if (cur == 0) issue_all(ra2, rb2); else issue_all(ra, rb);
-      }
-      compute(cur, no_hook);
+    // tail: the last r = n - t <= 4 tiles (t is even here: LDS stage and register set of every tile are static).
+    // Written out so that the compiler does not carry both register sets through a loop with runtime selection --
+    // for the 18-k-tile layer1 convolutions the tail is 4 of 18 tiles.
+    const int r = n - t;
+    if (r > 0) {   // tile t: LDS stage 0; tile t+1 waits in set 1, tile t+2 in set 0
+      if (r > 1) stage_set(1, ra2, rb2);
+      if (r > 3) issue_all(ra2, rb2);   // tile t+3 -> set 1
+      compute(0, no_hook);
+      __syncthreads();
+    }
+    if (r > 1) {   // tile t+1: stage 1
+      if (r > 2) stage_set(0, ra, rb);
+      compute(1, no_hook);
+      __syncthreads();
+    }
+    if (r > 2) {   // tile t+2: stage 0
+      if (r > 3) stage_set(1, ra2, rb2);
+      compute(0, no_hook);
+      __syncthreads();
+    }
+    if (r > 3) {   // tile t+3: stage 1
+      compute(1, no_hook);
       __syncthreads();
     }
   } else
