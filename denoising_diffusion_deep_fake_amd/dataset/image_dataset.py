@@ -43,10 +43,11 @@ class ImageDataset(Dataset):
 
 
 def synthetic_face_crops(batch, size, seed=1234, device="cpu"):
+    h, w = (size, size) if isinstance(size, int) else size  # an int, or (height, width)
     g = torch.Generator().manual_seed(seed)
-    low = torch.randn(batch, 3, size // 16, size // 16, generator=g) * 0.5
-    fine = torch.randn(batch, 3, size, size, generator=g) * 0.05
-    x = F.interpolate(low, size=(size, size), mode="bilinear", align_corners=False) + fine
+    low = torch.randn(batch, 3, h // 16, w // 16, generator=g) * 0.5
+    fine = torch.randn(batch, 3, h, w, generator=g) * 0.05
+    x = F.interpolate(low, size=(h, w), mode="bilinear", align_corners=False) + fine
     return torch.tanh(x).to(device)
 
 

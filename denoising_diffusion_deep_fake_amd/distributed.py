@@ -37,6 +37,26 @@ def init_process_group(backend=None):
     return world, rank, local
 
 
+def shared_seed(group=None):
+    """a data-shuffling seed that is the SAME on every rank: PL_GLOBAL_SEED when set (what Lightning's seed_everything
+    exports), otherwise rank 0's torch.initial_seed() broadcast to the others.  torch.initial_seed() itself is drawn per
+    process, so DistributedSampler(seed=initial_seed) would give every rank a different permutation: overlapping shards,
+    images never seen in an epoch."""
+    if os.environ.get("PL_GLOBAL_SEED") is not None:
+        return int(os.environ["PL_GLOBAL_SEED"]) % (1 << 31)
+    seed = int(torch.initial_seed() % (1 << 31))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        box = [seed]
+        if dist.get_backend(group) == "nccl":  # object collectives move through the device with RCCL
+            t = torch.tensor(box, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.broadcast(t, src=0, group=group)
+            box = [int(t.item())]
+        else:
+            dist.broadcast_object_list(box, src=0, group=group)
+        seed = int(box[0])
+    return seed
+
+
 class BucketAllReducer:
     """sum-all-reduce of gradient buckets, launched as they become ready, joined by wait()."""
 

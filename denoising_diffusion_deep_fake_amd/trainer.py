@@ -111,25 +111,58 @@ class CombinedLoader:
 def shard_loader(loader, world_size, rank, seed=0):
     """the same DataLoader over this rank's shard: DistributedSampler(shuffle as the original loader did,
     drop_last=False -> every rank sees ceil(N / world) samples, the tail padded by wrap-around as torch does)."""
-    from torch.utils.data import DataLoader, RandomSampler
+    from torch.utils.data import DataLoader, RandomSampler, SequentialSampler
     from torch.utils.data.distributed import DistributedSampler
     if world_size <= 1:
         return loader
+    if loader.batch_sampler is not None and type(loader.batch_sampler).__name__ != "BatchSampler":
+        raise TypeError(f"shard_loader: a custom batch_sampler ({type(loader.batch_sampler).__name__}) cannot be "
+                        f"sharded automatically; build the per-rank loader in train_dataloader()")
+    if type(loader.sampler) not in (RandomSampler, SequentialSampler):
+        # e.g. a WeightedRandomSampler over the `balance` difficulty classes: replacing it with a plain
+        # DistributedSampler would silently change what the run trains on
+        raise TypeError(f"shard_loader: sampler {type(loader.sampler).__name__} is neither sequential nor random; "
+                        f"shard it yourself (per-rank sampler) in train_dataloader()")
     shuffle = isinstance(loader.sampler, RandomSampler)
     sampler = DistributedSampler(loader.dataset, num_replicas=world_size, rank=rank, shuffle=shuffle, seed=seed,
                                  drop_last=False)
     kw = dict(batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers,
-              collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last)
+              collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=loader.drop_last,
+              timeout=loader.timeout, worker_init_fn=loader.worker_init_fn, generator=loader.generator,
+              pin_memory_device=getattr(loader, "pin_memory_device", ""))
     if loader.num_workers > 0:
-        kw.update(multiprocessing_context=loader.multiprocessing_context, persistent_workers=loader.persistent_workers)
+        kw.update(multiprocessing_context=loader.multiprocessing_context, persistent_workers=loader.persistent_workers,
+                  prefetch_factor=loader.prefetch_factor)
     return DataLoader(loader.dataset, **kw)
 
 
-def _set_epoch(loader, epoch):
-    loaders = loader.loaders.values() if isinstance(loader, CombinedLoader) else [loader]
-    for l in loaders:
-        if hasattr(getattr(l, "sampler", None), "set_epoch"):
-            l.sampler.set_epoch(epoch)
+def _set_epoch(loader, epoch, base_seed=0):
+    """per-epoch shuffling that a resumed run can REPLAY: DistributedSampler.set_epoch on sharded loaders; on a single
+    GPU a RandomSampler that has no generator of its own gets one seeded from (base_seed, epoch, loader index), so the
+    first `done` batches a mid-epoch resume passes over are the ones trained before the checkpoint."""
+    from torch.utils.data import RandomSampler
+    loaders = list(loader.loaders.values()) if isinstance(loader, CombinedLoader) else [loader]
+    for li, l in enumerate(loaders):
+        sampler = getattr(l, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        elif type(sampler) is RandomSampler and (sampler.generator is None or getattr(sampler, "_d3f_owned", False)):
+            sampler.generator = torch.Generator().manual_seed((base_seed * 1000003 + epoch * 131 + li) % (1 << 63))
+            sampler._d3f_owned = True
+
+
+def lightning_batches_done(ckpt):
+    """batches of the checkpoint's epoch that a pytorch_lightning 1.x run had completed when it saved mid-epoch
+    (`ModelCheckpoint(train_time_interval=...)`, d3f/train_deep_fake/lit_module.py:127-140), from its `loops` record;
+    None = saved at an epoch end (or no loop record)."""
+    try:
+        bp = ckpt["loops"]["fit_loop"]["epoch_loop.batch_progress"]
+        if bp.get("is_last_batch", False):
+            return None
+        done = int(bp["current"]["completed"])
+        return done if done > 0 else None
+    except (KeyError, TypeError, ValueError):
+        return None
 
 
 def _to_device(x, device):
@@ -164,6 +197,7 @@ class Trainer:
         self.module = None
         self._batches_done = None  # batches of the current epoch already trained (None between epochs)
         self._skip_batches = 0     # mid-epoch resume: batches of the first epoch to pass over
+        self._base_seed = None     # rank-independent base of data shuffling (see fit)
 
     # ---- checkpoints ------------------------------------------------------------------------------
     def save_checkpoint(self, path):
@@ -174,6 +208,7 @@ class Trainer:
             "global_step": self.global_step,
             # None: saved at the end of an epoch; n: saved mid-epoch after n batches (train_time_interval)
             "d3f_batches_done_in_epoch": self._batches_done,
+            "d3f_loader_seed": self._base_seed,  # base of the per-epoch shuffling (mid-epoch resume replays it)
             "pytorch-lightning_version": "1.9.5+d3f-hip",
             "state_dict": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
             "optimizer_states": [o.state_dict() for o in self.optimizers],
@@ -199,7 +234,11 @@ class Trainer:
         for s, sd in zip(self.lr_schedulers, ckpt.get("lr_schedulers", [])):
             s.load_state_dict(sd)
         self.global_step = int(ckpt.get("global_step", 0))
+        if ckpt.get("d3f_loader_seed") is not None:
+            self._base_seed = int(ckpt["d3f_loader_seed"])  # replay the interrupted epoch's permutation
         done = ckpt.get("d3f_batches_done_in_epoch")
+        if done is None and "d3f_batches_done_in_epoch" not in ckpt:
+            done = lightning_batches_done(ckpt)  # a checkpoint the reference (pytorch_lightning 1.x) wrote mid-epoch
         if done is None:
             self.current_epoch = int(ckpt.get("epoch", 0)) + 1  # saved at an epoch end: resume with the next epoch
             self._skip_batches = 0
@@ -281,10 +320,14 @@ class Trainer:
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
 
         loaders = model.train_dataloader()
+        if self._base_seed is None:  # (a resumed run keeps the checkpoint's)
+            self._base_seed = dist_utils.shared_seed()
         if self.world_size > 1:
             # one shard per rank (otherwise every rank would train on all the data and the all-reduce would average
-            # N copies of nearly the same gradient) and one noise / augmentation stream per rank
-            seed = int(torch.initial_seed() % (1 << 31))
+            # N copies of nearly the same gradient) and one noise / augmentation stream per rank.  The sampler seed
+            # must be the SAME on every rank (each takes indices[rank::world] of one permutation): torch.initial_seed()
+            # is per process, so it comes from PL_GLOBAL_SEED or is broadcast from rank 0 (distributed.shared_seed)
+            seed = self._base_seed
             if isinstance(loaders, dict):
                 loaders = {k: shard_loader(l, self.world_size, self.global_rank, seed) for k, l in loaders.items()}
             else:
@@ -295,9 +338,10 @@ class Trainer:
             cb.on_fit_start(self, model)
         done = False
         while self.current_epoch < self.max_epochs and not done:
-            _set_epoch(loader, self.current_epoch)
+            _set_epoch(loader, self.current_epoch, self._base_seed)
             skip, self._skip_batches = self._skip_batches, 0
             self._batches_done = 0
+            n_batches = len(loader) if self.limit_train_batches is None else min(len(loader), self.limit_train_batches)
             for batch_idx, batch in enumerate(loader):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
                     break
@@ -329,6 +373,13 @@ class Trainer:
                 if 0 < self.max_steps <= self.global_step:
                     done = True
                     break
+            if done and self._batches_done < n_batches:
+                # max_steps reached inside an epoch: the epoch is NOT complete -- no scheduler step, no validation, and
+                # the checkpoint the callbacks write now is marked mid-epoch (resume finishes this epoch at this LR)
+                for cb in callbacks:
+                    cb.on_train_epoch_end(self, model)
+                self._flush_metrics()
+                break
             self._batches_done = None
             for s in self.lr_schedulers:
                 s.step()

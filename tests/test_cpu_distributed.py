@@ -121,3 +121,41 @@ def test_trainer_shards_every_loader_per_rank():
         b0, b1 = ret[0][epoch]["b"], ret[1][epoch]["b"]
         assert not set(b0) & set(b1) and set(b0 + b1) == set(range(6))
     assert ret[0][0]["a"] != ret[0][1]["a"], "set_epoch must reshuffle"
+
+
+def _seed_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("PL_GLOBAL_SEED", None)
+    from torch.utils.data import DataLoader
+    from denoising_diffusion_deep_fake_amd.dataset.image_dataset import SyntheticFaceDataset
+    from denoising_diffusion_deep_fake_amd.distributed import init_process_group, shared_seed
+    from denoising_diffusion_deep_fake_amd.trainer import _set_epoch, shard_loader
+    init_process_group("gloo")
+    torch.seed()  # NOBODY seeded torch: every rank holds its own random initial_seed, as under torchrun
+    own = int(torch.initial_seed() % (1 << 31))
+    seed = shared_seed()  # what Trainer.fit hands to DistributedSampler
+    loader = shard_loader(DataLoader(SyntheticFaceDataset(11, 32), batch_size=2, shuffle=True), world, rank, seed)
+    _set_epoch(loader, 0, seed)
+    ret[rank] = (own, seed, [int(i) for b in loader for i in b["index"]])
+    dist.destroy_process_group()
+
+
+def test_unseeded_ranks_agree_on_the_sampler_seed():
+    """torch.initial_seed() differs per process, so the DistributedSampler seed must come from a
+    rank-independent source -- otherwise the ranks slice DIFFERENT permutations: overlapping shards, images never seen."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_seed_worker, (world, _free_port(), ret), world, seconds=90)
+    (own0, s0, i0), (own1, s1, i1) = ret[0], ret[1]
+    assert own0 != own1, "the premise: unseeded processes start from different seeds"
+    assert s0 == s1 == own0, "rank 0's seed, on every rank"
+    # 11 images over 2 ranks: ceil -> 6 each, one wrap-around duplicate; together they cover the dataset
+    assert len(i0) == len(i1) == 6 and set(i0) | set(i1) == set(range(11)) and len(set(i0) & set(i1)) <= 1
+
+
+def test_shared_seed_prefers_pl_global_seed(monkeypatch):
+    from denoising_diffusion_deep_fake_amd.distributed import shared_seed
+    monkeypatch.setenv("PL_GLOBAL_SEED", "1234")
+    assert shared_seed() == 1234

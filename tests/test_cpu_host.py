@@ -195,3 +195,80 @@ def test_combined_loader_reiterates_the_short_loader():
     assert len(got) == 5 and [g["a"][1] for g in got] == [0, 1, 2, 3, 4]
     assert [g["b"] for g in got] == [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0)]
     assert long.passes == 1 and short.passes == 3
+
+
+def test_shard_loader_keeps_loader_options_and_refuses_custom_samplers():
+    """generator / worker_init_fn / timeout survive the re-build; a sampler that is neither sequential nor
+    random (e.g. WeightedRandomSampler over the `balance` classes) is refused instead of silently replaced."""
+    import pytest
+    from torch.utils.data import DataLoader, WeightedRandomSampler
+    from torch.utils.data.distributed import DistributedSampler
+    from denoising_diffusion_deep_fake_amd.dataset.image_dataset import SyntheticFaceDataset
+    from denoising_diffusion_deep_fake_amd.trainer import shard_loader
+    ds = SyntheticFaceDataset(8, 32)
+    g = torch.Generator().manual_seed(5)
+
+    def init(worker_id):
+        pass
+    base = DataLoader(ds, batch_size=2, shuffle=True, generator=g, worker_init_fn=init, timeout=0)
+    sharded = shard_loader(base, 2, 1, seed=9)
+    assert isinstance(sharded.sampler, DistributedSampler) and sharded.sampler.seed == 9 and sharded.sampler.shuffle
+    assert sharded.generator is g and sharded.worker_init_fn is init and sharded.batch_size == 2
+    assert shard_loader(base, 1, 0) is base
+    weighted = DataLoader(ds, batch_size=2, sampler=WeightedRandomSampler([1.0] * 8, 8))
+    with pytest.raises(TypeError, match="WeightedRandomSampler"):
+        shard_loader(weighted, 2, 0)
+
+
+def test_single_gpu_epoch_permutation_is_replayable():
+    """mid-epoch resume passes over the first `done` batches, so the epoch's permutation must be a function
+    of (loader seed, epoch) -- also on one GPU, where the loader carries a plain RandomSampler."""
+    from torch.utils.data import DataLoader
+    from denoising_diffusion_deep_fake_amd.dataset.image_dataset import SyntheticFaceDataset
+    from denoising_diffusion_deep_fake_amd.trainer import _set_epoch
+
+    def epoch_indices(epoch, seed, global_seed):
+        torch.manual_seed(global_seed)  # another process, another global RNG state
+        loader = DataLoader(SyntheticFaceDataset(12, 32), batch_size=4, shuffle=True)
+        _set_epoch(loader, epoch, seed)
+        return [int(i) for b in loader for i in b["index"]]
+    assert epoch_indices(3, 77, 1) == epoch_indices(3, 77, 2)
+    assert epoch_indices(3, 77, 1) != epoch_indices(4, 77, 1)
+    assert epoch_indices(3, 77, 1) != epoch_indices(3, 78, 1)
+    own = torch.Generator().manual_seed(1)   # a generator the user supplied is left alone
+    loader = DataLoader(SyntheticFaceDataset(12, 32), batch_size=4, shuffle=True, generator=own)
+    _set_epoch(loader, 0, 5)
+    assert loader.sampler.generator is own
+
+
+def test_lightning_loop_record_gives_the_mid_epoch_position():
+    """a checkpoint the reference wrote with ModelCheckpoint(train_time_interval=...) (d3f/train_deep_fake/
+    lit_module.py:127-140) carries pytorch_lightning 1.x's `loops` record, not our d3f key"""
+    from denoising_diffusion_deep_fake_amd.trainer import lightning_batches_done
+    prog = {"total": {"ready": 130, "completed": 130, "started": 130, "processed": 130},
+            "current": {"ready": 30, "completed": 30, "started": 30, "processed": 30}, "is_last_batch": False}
+    ck = {"epoch": 1, "loops": {"fit_loop": {"epoch_loop.batch_progress": prog}}}
+    assert lightning_batches_done(ck) == 30
+    ck["loops"]["fit_loop"]["epoch_loop.batch_progress"] = dict(prog, is_last_batch=True)
+    assert lightning_batches_done(ck) is None
+    assert lightning_batches_done({"epoch": 1}) is None and lightning_batches_done({"loops": None}) is None
+
+
+def test_console_script_entry_point_resolves():
+    """the reference installs `d3f = d3f.main:cli` (setup.py:7-11); pyproject.toml declares the same script and the
+    packages it needs, and the target resolves to the click group with the reference's commands"""
+    import importlib
+    from pathlib import Path
+
+    import tomli
+    root = Path(__file__).resolve().parent.parent
+    meta = tomli.loads((root / "pyproject.toml").read_text())
+    target = meta["project"]["scripts"]["d3f"]
+    assert target == "d3f.main:cli"
+    mod, attr = target.split(":")
+    cli = getattr(importlib.import_module(mod), attr)
+    assert {"train", "denoise", "balance"} <= set(cli.commands)
+    found = set(meta["tool"]["setuptools"]["packages"]["find"]["include"])
+    assert {"d3f", "denoising_diffusion_deep_fake_amd*"} <= found
+    data = meta["tool"]["setuptools"]["package-data"]["denoising_diffusion_deep_fake_amd"]
+    assert any(p.endswith("libd3f_hip.so") for p in data) and any(p.endswith(".yml") for p in data)

@@ -1,5 +1,7 @@
-"""GPU, BASELINE.json full sizes (256x256, bs 16, f32), where the CPU oracle is too slow to be the checker:
-size-independent properties instead.
+"""GPU, BASELINE.json full sizes (256x256, bs 16, f32): size-independent properties of every layer shape and of the
+whole step.  (The oracle comparison AT these sizes -- every layer's output and activation against the float64 oracle,
+every gradient against the mask-pinned float64 oracle, 256x256 at bs 16 and bs 8, and the B=64 eval forward -- is
+tests/test_gpu_parity_layers.py; the properties here are cheap enough to run per layer shape and per mode.)
   * adjoint identities of each contraction trio:  <conv(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(dy; x)>
     (ties the forward, data-gradient and weight-gradient kernels of a layer shape to each other);
   * linearity of the forward kernel;

@@ -491,11 +491,30 @@ def test_ragged_last_batch_and_mid_epoch_resume(tmp_path):
     torch.manual_seed(2)
     lit = LitModule(**hp)
     assert len(lit.train_dataloader()) == 3
-    tr = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False, max_steps=2).fit(lit)
-    assert tr.global_step == 2
-    tr._batches_done = 2            # what ModelCheckpoint(train_time_interval=...) would have seen after batch 2
-    tr.current_epoch = 0
+    seen = []
+
+    def recording(module):
+        inner = module.training_step
+
+        def step(batch, batch_idx):
+            seen.append([int(i) for i in batch["index"]])
+            return inner(batch, batch_idx)
+        module.training_step = step
+        return module
+    tr = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False, max_steps=2).fit(recording(lit))
+    # max_steps ended the run INSIDE epoch 0: the epoch is not counted as done, the per-epoch cosine schedule has not
+    # stepped, and a checkpoint written now is marked mid-epoch (what ModelCheckpoint(train_time_interval=...) sees)
+    assert tr.global_step == 2 and tr.current_epoch == 0 and tr._batches_done == 2
+    assert tr.lr_schedulers[0].last_epoch == 0
     tr.save_checkpoint(tmp_path / "mid.ckpt")
+    first = [i for b in seen for i in b]
+    seen.clear()
+    torch.manual_seed(12345)  # a resumed process starts with another global RNG state
     tr2 = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False).fit(
-        LitModule.load_from_checkpoint(tmp_path / "mid.ckpt"), ckpt_path=tmp_path / "mid.ckpt")
+        recording(LitModule.load_from_checkpoint(tmp_path / "mid.ckpt")), ckpt_path=tmp_path / "mid.ckpt")
     assert tr2.global_step == 3 and tr2.current_epoch == 1   # one remaining (ragged) batch of epoch 0 was trained
+    # ... and it is the batch the interrupted epoch had NOT trained yet: the epoch's permutation is replayed from the
+    # checkpoint's loader seed, so every image is seen exactly once across the interruption
+    rest = [i for b in seen for i in b]
+    assert len(first) == 8 and len(rest) == 2 and sorted(first + rest) == list(range(10))
+    assert tr2.lr_schedulers[0].last_epoch == 1
