@@ -43,6 +43,9 @@ def parse():
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="N=1: price the data-parallel machinery on ONE GPU -- the same step plain and with the 4 gradient "
+                         "buckets all-reduced over a single-rank RCCL group (BucketAllReducer(force=True)); one JSON line")
     return ap.parse_args()
 
 
@@ -232,6 +235,90 @@ def extra_workload(args):
     print(json.dumps(res), flush=True)
 
 
+def dp_selftest(args):
+    """What the data-parallel path costs BEFORE any second GPU is involved (one rank, the real "nccl" == RCCL backend):
+    the backward pass runs bucket by bucket (d3f_unet_backward_nojoin), each bucket's flat gradient slice goes to an
+    asynchronous all_reduce ordered behind the engine's weight-gradient stream, Adam joins.  With one rank the sum is the
+    identity, so (a) the gradients must be bit-identical to the plain pass and (b) any slowdown is pure machinery:
+    per-bucket launches, RCCL's kernels taking wave slots, the joins.  A/B/A/B on one box, same process."""
+    import socket
+    import torch.distributed as dist
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    torch.manual_seed(0)
+    lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
+                    num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
+                    mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
+                    augment=False, precision=args.dtype).to(dev).train()
+    (opt,), _ = lit.configure_optimizers()
+    red = BucketAllReducer(force=True)
+    nb = 4
+    data = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
+
+    def mode(bucketed):
+        lit.model.set_grad_sync(red if bucketed else None)
+        opt.before_step = red.wait if bucketed else None
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = lit.training_step({"image": data[i % nb], "index": None}, i)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def grads_of(bucketed):  # one backward on a fixed batch and fixed noise, no optimiser step
+        mode(bucketed)
+        opt.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        lit.training_step({"image": data[0], "index": None}, 0).backward()
+        if bucketed:
+            red.wait()
+        torch.cuda.synchronize()
+        return lit.model.flat_grads.clone()
+
+    for i in range(args.warmup):
+        mode(i % 2 == 1)
+        step(i)
+    identical = bool(torch.equal(grads_of(False), grads_of(True)))
+    rounds, times = 3, {False: [], True: []}
+    for r in range(rounds):
+        for bucketed in (False, True):
+            mode(bucketed)
+            step(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                loss = step(i)
+            torch.cuda.synchronize()
+            times[bucketed].append(1e3 * (time.perf_counter() - t0) / args.steps)
+            log(f"dp-selftest round {r} {'bucketed+RCCL' if bucketed else 'plain'}: {times[bucketed][-1]:.3f} ms/step")
+    plain, buck = min(times[False]), min(times[True])
+    segs = lit.model._rt["last_engine"].seg_ranges
+    res = {"workload": f"dp-selftest: d3f train_denoiser step at N=1, plain vs 4 gradient buckets all-reduced over a "
+                       f"single-rank RCCL group, {args.size}x{args.size}, bs={args.batch}, {args.dtype}",
+           "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "steps": args.steps, "rounds": rounds,
+           "ms_per_step_plain": round(plain, 3), "ms_per_step_bucketed_rccl": round(buck, 3),
+           "dp_tax": round(buck / plain - 1.0, 4), "all_rounds_ms": {"plain": [round(t, 3) for t in times[False]],
+                                                                     "bucketed_rccl": [round(t, 3) for t in times[True]]},
+           "bucket_mb": [round(4e-6 * (e - b), 1) for b, e in segs],
+           "gradients_bit_identical_to_plain": identical, "final_loss": round(float(loss.item()), 5),
+           "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")}}
+    print(json.dumps(res), flush=True)
+    dist.destroy_process_group()
+    if not identical:
+        raise SystemExit("dp-selftest: bucketed gradients differ from the plain pass")
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) with no launcher around it: start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
@@ -265,7 +352,13 @@ def pmc_from_file(name, key, args):
     except (OSError, ValueError):
         return None, None
     src = {"file": "profiles/" + name, "collected_at_git_head": d.get("git_head"), "date": d.get("date"),
+           "csrc_digest": d.get("csrc_digest"),
            "note": "builder's rocprofv3 --pmc run of the same command, NOT measured by this run"}
+    from denoising_diffusion_deep_fake_amd import _lib
+    if d.get("csrc_digest") != _lib.source_digest():
+        # the kernels changed after the counters were collected: the figure would describe other code -> dropped
+        src["stale"] = "csrc/ sources differ from the ones the counters were collected on: fields dropped"
+        return None, src
     return key(d), src
 
 
@@ -273,6 +366,10 @@ def main():
     args = parse()
     if args.workload != "denoiser":
         return extra_workload(args)
+    if args.dp_selftest:
+        if args.gpus != 1:
+            raise SystemExit("--dp-selftest is the N=1 measurement")
+        return dp_selftest(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # before anything in this process touches the GPU
     from denoising_diffusion_deep_fake_amd import _lib
@@ -321,36 +418,32 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     use_events = not args.no_kernel_events
-    # An event pair costs ~8 us of stream time (its marker packets drain the queue), so only the launches of the
-    # roofline kernel -- conv_igemm_kernel: 47 forward + ~50 data-gradient launches per step -- are bracketed, and only
-    # on every EVERY-th timed step (>= 5 sampled steps whenever K >= 5).  The weight-gradient kernels are timed in a
-    # separate pass after the timed region.
-    EVERY = max(1, min(8, args.steps // 5))
     fence()
-    if use_events:
-        _lib.check(L.d3f_profile_enable(((args.steps + EVERY - 1) // EVERY) * 128 + 64))
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if use_events:
-            L.d3f_profile_classes(3 if i % EVERY == 0 else 0)
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+    # Kernel-level roofline figures: HIP events around every launch of a kernel class, in two passes of `diag` steps
+    # RIGHT AFTER the timed region (same process, same resident batches, same clocks) -- not inside it: an event pair
+    # costs ~8 us of stream time (its marker packets drain the queue), 97 pairs per step would tax `value` by ~2 %.
+    # Pass 1: the roofline kernel conv_igemm_kernel (+ its LDS-patch forms), 47 forward + ~50 data-gradient launches
+    # per step, on the caller's stream; pass 2: the weight-gradient kernels on the engine's side stream.
     ms, n, fl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
-    sampled = (args.steps + EVERY - 1) // EVERY
     diag = min(args.steps, 5)
+    sampled = diag
     if use_events:
-        L.d3f_profile_collect(ms, n, fl)
-        # diagnostic pass outside the timed region: the weight-gradient launches (side stream)
-        _lib.check(L.d3f_profile_classes(4))
-        _lib.check(L.d3f_profile_enable(diag * 64 + 64))
-        for i in range(diag):
-            loss = step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        ms2, n2, fl2 = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
-        L.d3f_profile_collect(ms2, n2, fl2)
-        ms[2], n[2], fl[2] = ms2[2], n2[2], fl2[2]
+        for classes in (3, 4):
+            _lib.check(L.d3f_profile_classes(classes))
+            _lib.check(L.d3f_profile_enable(diag * 128 + 64))
+            for i in range(diag):
+                loss = step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            ms2, n2, fl2 = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+            L.d3f_profile_collect(ms2, n2, fl2)
+            for k in ((0, 1) if classes == 3 else (2,)):
+                ms[k], n[k], fl[k] = ms2[k], n2[k], fl2[k]
         L.d3f_profile_classes(7)
         L.d3f_profile_enable(0)
     lossv = float(loss.item())
@@ -380,6 +473,11 @@ def main():
                                f"random-init weights, train-mode BatchNorm",
                    "image_size": args.size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "final_loss": round(lossv, 5),
+                   # what the collective layer saw (None at N=1: no process group, no exchange step)
+                   "backend": dist.get_backend() if world > 1 else None,
+                   "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                   # every tuning / debugging knob of libd3f_hip.so that was set in the environment of this run
+                   "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")},
                    "conv_gflop_per_image_step": round(step_flops / args.batch / 1e9, 3),
                    "whole_step_conv_tflops": round(whole, 2),
                    "whole_step_frac_of_peak": round(whole / peak, 4)},
@@ -396,26 +494,31 @@ def main():
         # their durations include that contention -- exactly what rocprofv3's kernel trace of this command reports
         per[1]["concurrent_with_weight_gradient_stream"] = True
         per[2]["concurrent_with_data_gradient_stream"] = True
-        per[2]["timed_region"] = False  # measured in a separate pass right after the timed steps
-        # ROOFLINE FIGURE: every launch of the dominant kernel (forward AND data gradient) on the sampled timed steps
+        for q in per:
+            q["timed_region"] = False  # measured in separate passes right after the timed steps (no event tax on `value`)
+        # ROOFLINE FIGURE: every launch of the dominant kernel (forward AND data gradient) of the sampled steps
         t_all, f_all, n_all = ms[0] + ms[1], fl[0] + fl[1], n[0] + n[1]
         ach = f_all / t_all / 1e9
-        traffic, tsrc = pmc_from_file("r02_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
-        busy, bsrc = pmc_from_file("r02_mfma_util.json", lambda d: next(
+        traffic, tsrc = pmc_from_file("r03_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
+        busy, bsrc = pmc_from_file("r03_mfma_util.json", lambda d: next(
             (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
+                           # forward launches alone (uncontended): comparable with round 1's forward-only figure
+                           "frac_forward": round(fl[0] / max(ms[0], 1e-9) / 1e9 / peak, 4),
                            "kernel": f"conv_igemm_kernel (+ conv_patch_kernel, its LDS-patch form for the 16-channel "
                                      f"full-resolution layers), ALL launches ({int(n[0]) // sampled} forward + "
                                      f"{int(n[1]) // sampled} data-gradient per step)",
-                           "launches": int(n_all), "sampled_steps": f"{sampled} of {args.steps} timed steps",
+                           "launches": int(n_all),
+                           "sampled_steps": f"{sampled} steps right after the {args.steps} timed steps (HIP events on the "
+                                            f"launch stream; the timed region itself carries no events)",
                            "avg_launch_us": round(1e3 * t_all / n_all, 2),
                            "flop_per_launch": round(f_all / n_all, 1),
                            "ms_per_step": round(t_all / sampled, 3),
                            "per_kernel": per}
         if tsrc is not None:
             out["roofline"]["traffic_source"] = tsrc
-        if busy is not None:
+        if bsrc is not None:
             out["roofline"]["pmc_from_file"] = dict(bsrc, mfma_pipe_busy=busy)
     else:
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,

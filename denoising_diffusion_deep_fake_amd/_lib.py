@@ -55,6 +55,9 @@ PROTOTYPES = {
     "d3f_unet_num_segments": (_i, [_p]),
     "d3f_unet_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "d3f_unet_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "d3f_unet_backward_nojoin": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "d3f_unet_side_stream": (_i, [_p, C.POINTER(_p)]),
+    "d3f_unet_backward_join": (_i, [_p, _p]),
     "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
     "d3f_unet_export_shape": (_i, [_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "d3f_conv_upsample_folded": (_i, [_i, _p]),
@@ -90,6 +93,18 @@ def header_symbols():
     text = HEADER_PATH.read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(d3f_[a-z0-9_]+)\s*\(", text)))
+
+
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources csrc/*.hip, csrc/*.h and the public header -- ties a
+    counter file under profiles/ to the code it was collected on (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted((_HERE / "csrc").glob("*.hip")) + sorted((_HERE / "csrc").glob("*.h")) + [HEADER_PATH]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def lib():

@@ -282,6 +282,22 @@ int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, 
             "unet_backward: segments [%d,%d)", seg_begin, seg_end);
   return h->e.backward(params, grad_out, grads, workspace, seg_begin, seg_end, (hipStream_t)stream);
 }
+int d3f_unet_backward_nojoin(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
+                             void* workspace, int seg_begin, int seg_end, void* stream) {
+  D3F_CHECK(h && params && grad_out && grads && workspace, "unet_backward_nojoin: null argument");
+  D3F_CHECK(seg_begin >= 0 && seg_end <= h->e.num_segments && seg_begin <= seg_end,
+            "unet_backward_nojoin: segments [%d,%d)", seg_begin, seg_end);
+  return h->e.backward(params, grad_out, grads, workspace, seg_begin, seg_end, (hipStream_t)stream, 0);
+}
+int d3f_unet_side_stream(d3f_unet_t h, void** stream_out) {
+  D3F_CHECK(h && stream_out, "unet_side_stream: null argument");
+  *stream_out = (void*)h->e.side_stream();
+  return 0;
+}
+int d3f_unet_backward_join(d3f_unet_t h, void* stream) {
+  D3F_CHECK(h, "unet_backward_join: null handle");
+  return h->e.backward_join((hipStream_t)stream);
+}
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream) {
   D3F_CHECK(h && name && workspace && out_nchw, "unet_export: null argument");
   return h->e.export_tensor(name, workspace, out_nchw, (hipStream_t)stream);

@@ -95,8 +95,15 @@ class UnetEngine {
   int pack_weights(const float* params, void* ws, hipStream_t s) const;
   int forward(const float* params, float* bnstats, const float* x, float* out, void* ws, int training,
               hipStream_t s) const;
+  // join != 0: every gradient of the segments is final on `s` when the call returns.  join == 0 (data-parallel
+  // callers): nothing makes `s` wait -- the segments' gradients are final on side_stream() once everything this call
+  // enqueued there has run (the side stream also waits for the caller's stream at the end of each segment, so an
+  // event recorded on it covers the BatchNorm / bias gradients written on the caller's stream too); backward_join()
+  // later makes a stream wait for all of it.
   int backward(const float* params, const float* dout, float* grads, void* ws, int seg_begin,
-               int seg_end, hipStream_t s) const;
+               int seg_end, hipStream_t s, int join = 1) const;
+  int backward_join(hipStream_t s) const;
+  hipStream_t side_stream() const;  // creates the engine's streams on first use; nullptr in D3F_SERIAL_BACKWARD mode
   // eval-mode forward on uint8 BGR frames with the K16 pre/post kernels fused in (in_channels = classes = 3);
   // use_graph: the launch sequence is captured once per set of pointers into a hipGraph and replayed
   int predict_u8(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
@@ -142,6 +149,8 @@ class UnetEngine {
   mutable hipStream_t side_ = nullptr;
   mutable std::vector<hipEvent_t> ev_dy_;  // one per weight-gradient launch of a backward pass
   mutable hipEvent_t ev_join_ = nullptr;
+  mutable hipEvent_t ev_seg_ = nullptr;   // "caller's stream has left the segment" (join == 0 calls)
+  mutable bool side_dirty_ = false;       // work was put on the side stream that no stream has joined yet
   // third stream: the decoder's skip-tensor data gradients.  They are consumed by the encoder stages, i.e. a whole
   // decoder later, so they leave the dependent chain and fill the machine next to its BatchNorm kernels
   // weight packing off the critical path: the layouts of encoder.conv1 / layer1 / layer2 (5 % of the parameters) are

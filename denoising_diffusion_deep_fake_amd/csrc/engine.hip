@@ -558,6 +558,7 @@ int UnetEngine::ensure_streams() const {
   static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
   D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
   D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  D3F_HIP(hipEventCreateWithFlags(&ev_seg_, hipEventDisableTiming));
   D3F_HIP(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
   D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
@@ -832,6 +833,7 @@ UnetEngine::~UnetEngine() {
   for (hipEvent_t e : ev_dy_)
     if (e) (void)hipEventDestroy(e);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (ev_seg_) (void)hipEventDestroy(ev_seg_);
   for (hipEvent_t e : ev_auxdy_)
     if (e) (void)hipEventDestroy(e);
   if (ev_aux_) (void)hipEventDestroy(ev_aux_);
@@ -849,12 +851,31 @@ UnetEngine::~UnetEngine() {
 // launch (WGroup), issued behind the group's last member; every unit owns its dY, so nothing on the main chain
 // ever waits for the side stream, which is joined before returning: after the call every gradient of the
 // segments is final on the caller's stream.
+static bool serial_backward() {
+  static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob: no side stream
+  return serial;
+}
+
+hipStream_t UnetEngine::side_stream() const {
+  if (serial_backward() || ensure_streams() != 0) return nullptr;
+  return side_;
+}
+
+int UnetEngine::backward_join(hipStream_t s) const {
+  if (side_ != nullptr && side_dirty_) {
+    D3F_HIP(hipEventRecord(ev_join_, side_));
+    D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+    side_dirty_ = false;
+  }
+  return 0;
+}
+
 int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
-                         int seg_begin, int seg_end, hipStream_t s) const {
+                         int seg_begin, int seg_end, hipStream_t s, int join) const {
   char* ws = reinterpret_cast<char*>(ws_);
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
-  static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob
+  const bool serial = serial_backward();
 #ifdef D3F_PROFILING
   // timing-only ablation (wrong gradients; profiling builds only): D3F_ABLATE_BACKWARD contains w (skip weight
   // gradients), d (data gradients), b (BatchNorm backward kernels) -- what each class costs on the critical path
@@ -1065,9 +1086,16 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
   }
   if (int rc = flush_pending()) return rc;
-  if (!serial && side_used) {  // join: every gradient of these segments is final on the caller's stream
-    D3F_HIP(hipEventRecord(ev_join_, side_));
-    D3F_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+  if (!serial && side_used) side_dirty_ = true;
+  if (!serial && !join) {
+    // data-parallel caller: the caller's stream (the critical path) is NOT held back.  The side stream waits for the
+    // caller's stream instead (BatchNorm / bias gradients of these segments are written there), so "everything on the
+    // side stream so far" == "every gradient of these segments is final": the collective waits on that, nothing else.
+    D3F_HIP(hipEventRecord(ev_seg_, s));
+    D3F_HIP(hipStreamWaitEvent(side_, ev_seg_, 0));
+    side_dirty_ = true;
+  } else if (!serial) {  // join: every gradient of these segments is final on the caller's stream
+    if (int rc = backward_join(s)) return rc;
   }
   if (aux_used && !aux_joined) {
     D3F_HIP(hipEventRecord(ev_aux_, aux_));

@@ -106,6 +106,7 @@ class _Engine:
         if os.environ.get("D3F_POISON_WORKSPACE"):  # test hook: any read-before-write shows up as NaN
             self.workspace.fill_(0xFF)
         self.packed_version = None
+        self._side = False    # not asked yet
         self.serial = 0       # bumped by every forward that overwrites this workspace
         self.in_use = False   # a recorded autograd graph still needs this workspace's activations
         self.fwd_flops = L.d3f_unet_forward_flops(self.h)
@@ -116,6 +117,15 @@ class _Engine:
             b, e = C.c_int64(), C.c_int64()
             check(L.d3f_unet_segment_range(self.h, s, C.byref(b), C.byref(e)))
             self.seg_ranges.append((b.value, e.value))
+
+    def side_stream(self, device):
+        """the engine's weight-gradient stream as a torch stream (None when the engine runs everything on the caller's
+        stream); owned by the engine, valid as long as it lives"""
+        if self._side is False:
+            sp = C.c_void_p()
+            check(_lib.lib().d3f_unet_side_stream(self.h, C.byref(sp)))
+            self._side = torch.cuda.ExternalStream(sp.value, device=device) if sp.value else None
+        return self._side
 
     def __del__(self):
         try:
@@ -391,11 +401,23 @@ class Unet(nn.Module):
             check(L.d3f_unet_backward(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target), ptr(eng.workspace),
                                       0, eng.nseg, stream_ptr()))
         else:
+            # Data parallel: bucket k's collective must wait for bucket k's gradients -- and nothing else may wait for
+            # anything.  The gradients become final on the engine's SIDE stream (weight gradients run there; it also
+            # waits for this stream at the end of each bucket), so the hook is called with the side stream current:
+            # torch.distributed orders a collective behind the current stream at the time of the call.  This stream
+            # (the dependent BatchNorm-backward -> data-gradient chain, the critical path) goes straight on with bucket
+            # k+1; one join after the last bucket orders the optimiser behind the weight gradients.
+            side = eng.side_stream(grad_out.device)
             for s in range(eng.nseg):
-                check(L.d3f_unet_backward(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target),
-                                          ptr(eng.workspace), s, s + 1, stream_ptr()))
+                check(L.d3f_unet_backward_nojoin(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target),
+                                                 ptr(eng.workspace), s, s + 1, stream_ptr()))
                 b, e = eng.seg_ranges[s]
-                sync(s, target[b:e])
+                if side is None:  # D3F_SERIAL_BACKWARD: everything is on this stream
+                    sync(s, target[b:e])
+                else:
+                    with torch.cuda.stream(side):
+                        sync(s, target[b:e])
+            check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
         ptable = self._table()[0]
         for (name, shape, off), p in zip(ptable, params):
             if not p.requires_grad:

@@ -103,6 +103,18 @@ int d3f_unet_num_segments(d3f_unet_t h);
 int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end);
 int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
                       void* workspace, int seg_begin, int seg_end, void* stream);
+/* Data-parallel form (BASELINE.json: "RCCL all-reduce of gradients over xGMI overlapped with the backward pass";
+ * the reference itself is single-device, d3f/train_deep_fake/start_training.py:43-48).  d3f_unet_backward makes the
+ * caller's stream -- the critical path of the backward pass -- wait for the engine's weight-gradient stream before it
+ * returns; called once per bucket that stalls the chain four times.  d3f_unet_backward_nojoin enqueues the same work
+ * and makes NOTHING wait on the caller's stream: the gradients of the segments are final on the engine's side stream
+ * (d3f_unet_side_stream; NULL in D3F_SERIAL_BACKWARD mode = the caller's stream) once everything enqueued there so far
+ * has run, so a collective ordered behind THAT stream overlaps the remaining segments.  d3f_unet_backward_join makes
+ * `stream` wait for the side stream (call once, before the optimiser reads the gradients). */
+int d3f_unet_backward_nojoin(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
+                             void* workspace, int seg_begin, int seg_end, void* stream);
+int d3f_unet_side_stream(d3f_unet_t h, void** stream_out);
+int d3f_unet_backward_join(d3f_unet_t h, void* stream);
 /* debugging / tests: copy an internal activation ("<conv name>:y" raw conv output, ":a" post
  * BN+ReLU, ":da" its gradient) to NCHW f32 */
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream);

@@ -1,4 +1,9 @@
+"""untraced host-loop measurement: how far ahead of the GPU the Python-driven launch loop runs.
+    python3 profiles/tools/hostprobe.py [dtype=f32] [size=256] [batch=16]"""
 import time, torch, sys, os
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"
+SIZE = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
 from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
@@ -6,12 +11,12 @@ from denoising_diffusion_deep_fake_amd.distributed import DataParallel
 from denoising_diffusion_deep_fake_amd import _lib
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-lit = LitModule(batch_size=16, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100, num_workers=0,
+lit = LitModule(batch_size=BATCH, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100, num_workers=0,
                 encoder_name="resnet34", noise_exponential_sampling_lambda=5, mean=[128]*3, std=[128]*3,
-                synthetic=True, image_size=256, augment=False, precision="f32").to(dev).train()
+                synthetic=True, image_size=SIZE, augment=False, precision=DTYPE).to(dev).train()
 (opt,), _ = lit.configure_optimizers()
 DataParallel(lit.model, opt)
-data = [synthetic_face_crops(16, 256, seed=1234 + i, device=dev) for i in range(4)]
+data = [synthetic_face_crops(BATCH, SIZE, seed=1234 + i, device=dev) for i in range(4)]
 T = {"zero": 0.0, "train_step": 0.0, "backward": 0.0, "opt": 0.0}
 def step(i, rec):
     t0 = time.perf_counter(); opt.zero_grad(set_to_none=True)
@@ -29,7 +34,7 @@ for i in range(N): step(i, True)
 th = time.perf_counter() - t0
 torch.cuda.synchronize()
 tt = time.perf_counter() - t0
-print(f"host loop {1e3*th/N:.2f} ms/step, with final sync {1e3*tt/N:.2f} ms/step")
+print(f"[{DTYPE} {SIZE}x{SIZE} bs{BATCH}] host loop (enqueue only) {1e3*th/N:.2f} ms/step, GPU-paced (with final sync) {1e3*tt/N:.2f} ms/step")
 print({k: round(1e3 * v / N, 3) for k, v in T.items()})
 # host-only cost: same loop while the GPU is idle at each phase start (sync before each step)
 T = {k: 0.0 for k in T}

@@ -8,6 +8,13 @@ import json
 import sys
 
 
+
+def _digest():
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from denoising_diffusion_deep_fake_amd import _lib
+    return _lib.source_digest()
+
 def main(out_dir, json_path, head="unknown", date=""):
     path = glob.glob(f"{out_dir}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -31,7 +38,7 @@ def main(out_dir, json_path, head="unknown", date=""):
                      "mfma_mops_f32": c["SQ_INSTS_VALU_MFMA_MOPS_F32"]})
         print(rows[-1])
     json.dump({"source": "profiles/tools/collect_mfma.sh (6 training steps incl. warm-up, 256x256 bs16 f32; kernels "
-                         "serialised by PMC collection)", "git_head": head, "date": date, "kernels": rows},
+                         "serialised by PMC collection)", "git_head": head, "csrc_digest": _digest(), "date": date, "kernels": rows},
               open(json_path, "w"), indent=1)
 
 

@@ -13,6 +13,13 @@ import json
 import sys
 
 
+
+def _digest():
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from denoising_diffusion_deep_fake_amd import _lib
+    return _lib.source_digest()
+
 def short(name):
     name = name.replace("void d3f::", "").replace("d3f::", "")
     return name.split("<")[0].split("(")[0]
@@ -66,11 +73,11 @@ def main(out_dir, traffic_json, kernels_json, head, date):
     src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/tools/collect_traffic.sh over `bench.py --steps 4 "
            "--warmup 2 --no-cpu-baseline --no-kernel-events --no-alt` (256x256, bs 16, f32); bytes = (2*FETCH_SIZE + "
            "WRITE_SIZE) KB per MI355X_MICROARCH.md; durations from the FETCH_SIZE pass (kernels serialised)")
-    json.dump({"source": src, "git_head": head, "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
+    json.dump({"source": src, "git_head": head, "csrc_digest": _digest(), "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
                "kernels": kernels}, open(kernels_json, "w"), indent=1)
     # the roofline kernel family: conv_igemm_kernel and its LDS-patch form for the 16-channel full-resolution layers
     ci = [a + b for a, b in zip(agg["conv_igemm_kernel"], agg.get("conv_patch_kernel", [0, 0.0, 0.0, 0.0]))]
-    res = {"kernel": "conv_igemm_kernel + conv_patch_kernel (ALL launches: forward + data gradient)", "git_head": head,
+    res = {"kernel": "conv_igemm_kernel + conv_patch_kernel (ALL launches: forward + data gradient)", "git_head": head, "csrc_digest": _digest(),
            "date": date,
            "launches_sampled": ci[0], "launches_per_step": round(ci[0] / n, 1),
            "fetch_size_kb_mean": round(ci[1] / ci[0], 1), "write_size_kb_mean": round(ci[2] / ci[0], 1),
