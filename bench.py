@@ -210,17 +210,41 @@ def extra_workload(args):
             return loss
         images_per_step, name = 2 * bs, f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain"
     else:
+        # BASELINE.json configs[4]: 50 sequential eval-mode forwards of a batch of 64 at 256x256, the output fed back
+        # as the next input (clamped: the "re-noise" stand-in of SURVEY.md 8d), the denoise step replayed from a
+        # hipGraph captured once (Unet.forward_graph); the eager loop is timed next to it and must agree bitwise
         from denoising_diffusion_deep_fake_amd import Unet
         net = Unet("resnet34", None, 3, 3, None, compute_dtype=args.dtype).to(dev).eval()
-        x = synthetic_face_crops(64, args.size, seed=3, device=dev)
+        x0 = synthetic_face_crops(64, args.size, seed=3, device=dev)
+        xbuf, ybuf = torch.empty_like(x0), torch.empty_like(x0)
+
+        @torch.no_grad()
+        def eager(i):
+            y = x0
+            for _ in range(50):
+                y = net(y).clamp_(-1.0, 1.0)  # keep the fed-back "image" in range (random-init weights)
+            return y
 
         @torch.no_grad()
         def step(i):
-            y = x
+            xbuf.copy_(x0)
             for _ in range(50):
-                y = net(y).clamp_(-1.0, 1.0)  # keep the fed-back "image" in range (random-init weights)
-            return y.mean()
-        images_per_step, name = 64, "50 eval-mode forwards (BatchNorm folded) of a batch of 64, output fed back"
+                net.forward_graph(xbuf, out=ybuf)
+                torch.clamp(ybuf, -1.0, 1.0, out=xbuf)
+            return xbuf.mean()
+        for i in range(max(args.warmup, 1)):
+            ref = eager(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ref = eager(i)
+        torch.cuda.synchronize()
+        eager_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        step(0)
+        bitwise = bool(torch.equal(ref, xbuf))
+        images_per_step, name = 64, ("50 eval-mode forwards (BatchNorm folded) of a batch of 64, output fed back; "
+                                     "denoise step replayed from a hipGraph")
+        extra = {"ms_per_step_eager": round(eager_ms, 3), "replay_equals_eager_bitwise": bitwise}
     for i in range(args.warmup):
         out = step(i)
     torch.cuda.synchronize()
@@ -232,7 +256,11 @@ def extra_workload(args):
     res = {"workload": name, "dtype": args.dtype, "image_size": args.size, "steps": args.steps,
            "ms_per_step": round(1e3 * dt / args.steps, 3),
            "images_per_sec": round(images_per_step * args.steps / dt, 2), "last": float(out.item())}
+    if args.workload == "sample50":
+        res.update(extra)
     print(json.dumps(res), flush=True)
+    if args.workload == "sample50" and not extra["replay_equals_eager_bitwise"]:
+        raise SystemExit("sample50: hipGraph replay differs from the eager loop")
 
 
 def dp_selftest(args):

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "d3f_unet_backward_flops": (_dbl, [_p]),
     "d3f_unet_pack_weights": (_i, [_p, _p, _p, _p]),
     "d3f_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _p]),
+    "d3f_unet_forward_graph": (_i, [_p, _p, _p, _p, _p, _p, _p]),
     "d3f_noise_blend_fixed": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
     "d3f_l1_per_image_workspace_bytes": (_sz, [_i]),
     "d3f_l1_per_image": (_i, [_p, _p, _p, _p, _i, _i64, _p]),

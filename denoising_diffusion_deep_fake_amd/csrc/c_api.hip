@@ -262,6 +262,11 @@ int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const fl
   D3F_CHECK(h && params && bnstats && x && out && workspace, "unet_forward: null argument");
   return h->e.forward(params, bnstats, x, out, workspace, training, (hipStream_t)stream);
 }
+int d3f_unet_forward_graph(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
+                           void* workspace, void* stream) {
+  D3F_CHECK(h && params && bnstats && x && out && workspace, "unet_forward_graph: null argument");
+  return h->e.forward_graph(params, bnstats, x, out, workspace, (hipStream_t)stream);
+}
 int d3f_unet_predict_u8(d3f_unet_t h, const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
                         const float mean[3], const float std[3], void* workspace, int use_graph, void* stream) {
   D3F_CHECK(h && params && bnstats && bgr_in && bgr_out && mean && std && workspace, "predict_u8: null argument");

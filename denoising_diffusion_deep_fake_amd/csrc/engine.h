@@ -108,6 +108,9 @@ class UnetEngine {
   // use_graph: the launch sequence is captured once per set of pointers into a hipGraph and replayed
   int predict_u8(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
                  const float mean[3], const float stdv[3], void* ws, int use_graph, hipStream_t s) const;
+  // eval-mode forward (f32 NCHW in / out) replayed from a hipGraph captured once per set of pointers -- the
+  // "hipGraph-captured denoise step" of BASELINE.json configs[4]; bit-identical to forward(training = 0)
+  int forward_graph(const float* params, float* bnstats, const float* x, float* out, void* ws, hipStream_t s) const;
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
   int export_shape(const char* name, int32_t dims[3]) const;
 
@@ -171,11 +174,18 @@ class UnetEngine {
   int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
   int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
                           const float mean255[3], const float std255[3], char* ws, hipStream_t s) const;
+  // captured graphs: one slot per entry point; a slot is re-captured when the pointers / constants it baked in change
+  struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    const void* key[5] = {};
+    float cst[6] = {};
+  };
+  template <typename F>
+  int graph_replay(GraphSlot& slot, const void* const key[5], const float cst[6], hipStream_t s, F&& launches) const;
+  int wait_for_packed_weights(hipStream_t s) const;
   mutable hipStream_t gstream_ = nullptr;
-  mutable hipGraphExec_t gexec_ = nullptr;
+  mutable GraphSlot g_predict_, g_eval_;
   mutable hipEvent_t ev_gin_ = nullptr, ev_gout_ = nullptr;
-  mutable const void* gkey_[5] = {};
-  mutable float gconst_[6] = {};
   size_t head_nchw_off = 0;
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;

@@ -778,7 +778,25 @@ int UnetEngine::predict_u8(const float* params_, float* bnstats, const uint8_t* 
     s255[c] = stdv[c] * 255.0f;
   }
   if (!use_graph) return predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, s);
-  if (pack_mid_pending_) {  // not inside the capture: the replay stream is ordered after the caller's stream below
+  // hipGraph path: at B = 1 the ~100 launches of an eval forward are launch-bound; capture them once
+  const void* key[5] = {params_, bnstats, bgr_in, bgr_out, ws_};
+  const float cst[6] = {m255[0], m255[1], m255[2], s255[0], s255[1], s255[2]};
+  return graph_replay(g_predict_, key, cst, s, [&](hipStream_t gs) {
+    return predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, gs);
+  });
+}
+
+int UnetEngine::forward_graph(const float* params_, float* bnstats, const float* x, float* out, void* ws_,
+                              hipStream_t s) const {
+  const void* key[5] = {params_, bnstats, x, out, ws_};
+  const float cst[6] = {0, 0, 0, 0, 0, 0};
+  return graph_replay(g_eval_, key, cst, s, [&](hipStream_t gs) { return forward(params_, bnstats, x, out, ws_, 0, gs); });
+}
+
+// the packed weights of the later layers may still be in flight on the side stream: order `s` behind them (outside
+// any capture: the replay stream is ordered after `s`)
+int UnetEngine::wait_for_packed_weights(hipStream_t s) const {
+  if (pack_mid_pending_) {
     D3F_HIP(hipStreamWaitEvent(s, ev_pack_mid_, 0));
     pack_mid_pending_ = false;
   }
@@ -786,47 +804,52 @@ int UnetEngine::predict_u8(const float* params_, float* bnstats, const uint8_t* 
     D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
     pack_pending_ = false;
   }
+  return 0;
+}
 
-  // hipGraph path: at B = 1 the ~100 launches of an eval forward are launch-bound; capture them once
+template <typename F>
+int UnetEngine::graph_replay(GraphSlot& slot, const void* const key[5], const float cst[6], hipStream_t s,
+                             F&& launches) const {
+  if (int rc = wait_for_packed_weights(s)) return rc;
   if (gstream_ == nullptr) {
     D3F_HIP(hipStreamCreateWithFlags(&gstream_, hipStreamNonBlocking));
     D3F_HIP(hipEventCreateWithFlags(&ev_gin_, hipEventDisableTiming));
     D3F_HIP(hipEventCreateWithFlags(&ev_gout_, hipEventDisableTiming));
   }
-  const void* key[5] = {params_, bnstats, bgr_in, bgr_out, ws_};
-  const float cst[6] = {m255[0], m255[1], m255[2], s255[0], s255[1], s255[2]};
-  const bool same = gexec_ != nullptr && memcmp(key, gkey_, sizeof(key)) == 0 && memcmp(cst, gconst_, sizeof(cst)) == 0;
+  const bool same = slot.exec != nullptr && memcmp(key, slot.key, sizeof(slot.key)) == 0 &&
+                    memcmp(cst, slot.cst, sizeof(slot.cst)) == 0;
   if (!same) {
-    if (gexec_) {
-      (void)hipGraphExecDestroy(gexec_);
-      gexec_ = nullptr;
+    if (slot.exec) {
+      (void)hipGraphExecDestroy(slot.exec);
+      slot.exec = nullptr;
     }
     hipGraph_t graph = nullptr;
     D3F_HIP(hipStreamBeginCapture(gstream_, hipStreamCaptureModeThreadLocal));
-    const int rc = predict_u8_launches(params_, bnstats, bgr_in, bgr_out, m255, s255, ws, gstream_);
+    const int rc = launches(gstream_);
     const hipError_t e = hipStreamEndCapture(gstream_, &graph);
     if (rc != 0) {
       if (graph) (void)hipGraphDestroy(graph);
       return rc;
     }
     D3F_HIP(e);
-    const hipError_t ei = hipGraphInstantiate(&gexec_, graph, nullptr, nullptr, 0);
+    const hipError_t ei = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     D3F_HIP(ei);
-    memcpy(gkey_, key, sizeof(key));
-    memcpy(gconst_, cst, sizeof(cst));
+    memcpy(slot.key, key, sizeof(slot.key));
+    memcpy(slot.cst, cst, sizeof(slot.cst));
   }
-  // order the replay after the caller's stream (input frame, packed weights) and the caller after the replay
+  // order the replay after the caller's stream (input, packed weights) and the caller after the replay
   D3F_HIP(hipEventRecord(ev_gin_, s));
   D3F_HIP(hipStreamWaitEvent(gstream_, ev_gin_, 0));
-  D3F_HIP(hipGraphLaunch(gexec_, gstream_));
+  D3F_HIP(hipGraphLaunch(slot.exec, gstream_));
   D3F_HIP(hipEventRecord(ev_gout_, gstream_));
   D3F_HIP(hipStreamWaitEvent(s, ev_gout_, 0));
   return 0;
 }
 
 UnetEngine::~UnetEngine() {
-  if (gexec_) (void)hipGraphExecDestroy(gexec_);
+  if (g_predict_.exec) (void)hipGraphExecDestroy(g_predict_.exec);
+  if (g_eval_.exec) (void)hipGraphExecDestroy(g_eval_.exec);
   if (ev_gin_) (void)hipEventDestroy(ev_gin_);
   if (ev_gout_) (void)hipEventDestroy(ev_gout_);
   if (gstream_) (void)hipStreamDestroy(gstream_);

@@ -459,6 +459,38 @@ class Unet(nn.Module):
         return self._run_forward(eng, xin, training=self.training)
 
     @torch.no_grad()
+    def forward_graph(self, x, out=None):
+        """Eval-mode forward replayed from a hipGraph (BASELINE.json configs[4]: "hipGraph-captured denoise step"; the
+        reference's frame loop is d3f/script_tools/put_video_through_fake_model.py:111-119).  The graph is captured on
+        the first call per (x, out) buffer pair and bakes those pointers in, so a sampling loop passes the SAME two
+        buffers every iteration (write the next input into `x` in place); results are bit-identical to `self(x)` in
+        eval mode.  Parameter updates between calls are picked up (values are read at replay time)."""
+        if self.training:
+            raise D3FError("forward_graph is the eval-mode (BatchNorm folded) forward: call .eval() first")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"Expected input [B, {self.in_channels}, H, W], got {list(x.shape)}")
+        self.check_input_shape(x)
+        if x.device.type != "cuda":
+            raise D3FError("d3f Unet runs on an MI355X (HIP) device only; there is no CPU fallback")
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("forward_graph bakes the input pointer into the graph: pass a contiguous float32 tensor")
+        shape = (x.shape[0], self.classes, x.shape[2], x.shape[3])
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {shape} on the input's device")
+        self._ensure_flat(x.device)
+        eng = self._engine(x.shape[0], x.shape[2], x.shape[3], x.device)
+        self._pack_if_needed(eng)
+        rt = self._rt
+        eng.serial += 1
+        rt["last_engine"] = eng
+        check(_lib.lib().d3f_unet_forward_graph(eng.h, ptr(rt["flat"]), ptr(rt["flat_bn"]), ptr(x), ptr(out),
+                                                ptr(eng.workspace), stream_ptr()))
+        eng.keep_graph = (x, out)  # the captured graph holds these pointers: keep them alive with the engine
+        return out
+
+    @torch.no_grad()
     def predict_u8(self, frames_bgr, mean, std, graph=True, out=None):
         """Inference on uint8 BGR frames ([H,W,3] or [B,H,W,3] on the HIP device) -> uint8 BGR frames.
 

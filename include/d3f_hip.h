@@ -87,6 +87,14 @@ int d3f_unet_pack_weights(d3f_unet_t h, const float* params, void* workspace, vo
  * updates bnstats (momentum 0.1) and keeps what backward needs in the workspace. */
 int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
                      void* workspace, int training, void* stream);
+/* The eval-mode forward (training == 0 above: BatchNorm running statistics folded into the conv epilogues) replayed
+ * from a hipGraph that is captured on first use per set of pointers (params, bnstats, x, out, workspace) -- the
+ * "hipGraph-captured denoise step" of BASELINE.json configs[4]; the reference's frame loop is
+ * d3f/script_tools/put_video_through_fake_model.py:111-119 -> d3f/train_deep_fake/lit_module.py:259-270.  Results are
+ * bit-identical to d3f_unet_forward(training = 0); parameter VALUES are read at replay time (only pointers are baked
+ * in), so the graph survives optimiser / EMA updates followed by d3f_unet_pack_weights. */
+int d3f_unet_forward_graph(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
+                           void* workspace, void* stream);
 /* Inference entry behind LitModule.predict_fake_for_single_frame (d3f/train_deep_fake/lit_module.py:259-300):
  * uint8 BGR frames [B][H][W][3] in device memory -> eval-mode forward (BatchNorm folded into the conv
  * epilogues) -> uint8 BGR frames, with cv2_to_tensor_normalised (:272-283: BGR->RGB, (x - mean*255) / (std*255))

@@ -227,3 +227,35 @@ def test_eval_fused_epilogue_matches_train_path_apply_at_b64():
             err = ((e - train_a[n]).norm() / train_a[n].norm()).item()
             assert err < 2e-5, (n, err)
         assert ((out_eval - out_train).norm() / out_train.norm()).item() < 2e-5
+
+
+@pytest.mark.timeout(600)
+def test_sample50_hipgraph_replay_equals_eager_loop_bitwise():
+    """BASELINE.json configs[4] as written: 50 eval-mode forwards of B=64 at 256x256, output fed back, with the denoise
+    step replayed from ONE captured hipGraph (Unet.forward_graph, d3f_unet_forward_graph) -- every one of the 50
+    replays must equal the eager forward of the same input bit for bit, and an optimiser-style parameter update between
+    two loops must be picked up by the already-captured graph (only pointers are baked in).  Reference loop:
+    d3f/script_tools/put_video_through_fake_model.py:111-119 -> d3f/train_deep_fake/lit_module.py:259-270."""
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd._lib import D3FError
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    torch.manual_seed(5)
+    net = Unet("resnet34", None, 3, 3, None).cuda()
+    with pytest.raises(D3FError):
+        net.train().forward_graph(torch.zeros(1, 3, 32, 32, device="cuda"))
+    net.eval()
+    x0 = synthetic_face_crops(64, 256, seed=3, device="cuda")
+    xbuf, ybuf = torch.empty_like(x0), torch.empty_like(x0)
+    with torch.no_grad():
+        for loop in range(2):
+            xbuf.copy_(x0)
+            y = x0
+            for it in range(50):
+                y = net(y).clamp_(-1.0, 1.0)                      # eager: ~50 launches from Python per forward
+                out = net.forward_graph(xbuf, out=ybuf)           # replay of the graph captured at it == 0, loop == 0
+                assert out.data_ptr() == ybuf.data_ptr()
+                torch.clamp(ybuf, -1.0, 1.0, out=xbuf)
+                assert torch.equal(y, xbuf), (loop, it)
+            assert torch.isfinite(y).all() and y.abs().max() > 0
+            net.flat_params.mul_(1.01)    # what an optimiser / EMA update does: values change, pointers stay
+            net.mark_params_changed()
