@@ -9,8 +9,9 @@
 // streaming pass: no second launch, no atomics, no fences, and every workgroup computes bit-identical coefficients.
 // Row block 0 of each slab also writes the coefficients (the backward pass and the data-gradient epilogues read them)
 // and updates the running statistics / dgamma, dbeta.  Replaces ATen's batch_norm / batch_norm_backward under
-// segmentation_models_pytorch.Unet (d3f/train_denoiser/lit_module.py:46-52); fp32 tensors only (the bf16 mode keeps
-// the separate launches), channel counts that are a multiple of 32, at most BNF_MAX_ROWS partial rows.
+// segmentation_models_pytorch.Unet (d3f/train_denoiser/lit_module.py:46-52); fp32 or bf16 tensors (statistics,
+// coefficients and arithmetic are fp32 / f64 in both; bf16 rows are 8-byte vectors per thread), channel counts that are
+// a multiple of 32, at most BNF_MAX_ROWS partial rows.
 #include "common.h"
 #include "pointwise.h"
 
@@ -28,7 +29,23 @@ constexpr int BNF_MAX_ROWS = 1024;  // partial rows a workgroup is asked to redu
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   static const bool off = getenv("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
   static const int max_rows = getenv("D3F_BN_FUSED_MAX_ROWS") ? atoi(getenv("D3F_BN_FUSED_MAX_ROWS")) : BNF_MAX_ROWS;  // tuning knob
-  return !off && dtype == D3F_F32 && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= max_rows;
+  return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= max_rows;
+}
+
+// four consecutive channels of one tensor row: 16 bytes (f32) / 8 bytes (bf16) per thread
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float4& v) {
+  const uint32_t a = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+  const uint32_t b = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
 }
 
 // sums the partial rows [rows][ld][2] of channels [c0, c0 + 32) in f64: thread (rl = tid / 16, q = tid % 16) owns the
@@ -81,13 +98,14 @@ __device__ __forceinline__ void slab_reduce(const float* __restrict__ partial, i
 // forward: statistics -> (mean, invstd, scale, shift, running stats) -> out = [relu](y * scale + shift [+ residual])
 // grid = (row blocks, C / 32); residual forms as bn_apply_kernel (pointwise.hip)
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     const float* __restrict__ stats, int stat_rows, int C, int Cpad, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
     float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
-    const float* __restrict__ y, const float* __restrict__ res, const float* __restrict__ yr,
-    const float* __restrict__ scale_r, const float* __restrict__ shift_r, int relu, float* __restrict__ out,
+    const T* __restrict__ y, const T* __restrict__ res, const T* __restrict__ yr,
+    const float* __restrict__ scale_r, const float* __restrict__ shift_r, int relu, T* __restrict__ out,
     long rows, long rows_per_block) {
   __shared__ double red[16][64];
   __shared__ double tot[64];
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  const float* __restrict__ second = res != nullptr ? res : yr;
+  const T* __restrict__ second = res != nullptr ? res : yr;
   constexpr int U = 4;
   for (long r = r0 + rr; r < r1; r += 32 * U) {
     float4 a[U], b[U];
@@ -140,8 +158,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     for (int u = 0; u < U; ++u) {
       const long row = r + 32 * u;
       if (row < r1) {
-        a[u] = *reinterpret_cast<const float4*>(y + row * C + cc);
-        if (second != nullptr) b[u] = *reinterpret_cast<const float4*>(second + row * C + cc);
+        a[u] = ld4<T>(y + row * C + cc);
+        if (second != nullptr) b[u] = ld4<T>(second + row * C + cc);
       }
     }
 #pragma unroll
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
       }
-      *reinterpret_cast<float4*>(out + row * C + cc) = make_float4(x[0], x[1], x[2], x[3]);
+      st4<T>(out + row * C + cc, make_float4(x[0], x[1], x[2], x[3]));
     }
   }
 }
@@ -176,20 +194,26 @@ static long rows_per_block_for(long rows, int slabs) {
   return std::max(32L, rpb);
 }
 
-int bn_finalize_apply_launch(const float* stats, int stat_rows, int C, int Cpad, long count, const float* gamma,
+int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C, int Cpad, long count, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, float* scale, float* shift,
                              const void* y, const void* res, const void* yr, const float* scale_r,
                              const float* shift_r, int relu, void* out, long rows, hipStream_t stream) {
-  D3F_CHECK(bn_fused_finalize_ok(D3F_F32, stat_rows, C), "bn_finalize_apply: C=%d, %d partial rows", C, stat_rows);
+  D3F_CHECK(bn_fused_finalize_ok(dtype, stat_rows, C), "bn_finalize_apply: C=%d, %d partial rows", C, stat_rows);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
   const long rpb = rows_per_block_for(rows, slabs);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
-  hipLaunchKernelGGL(bn_finalize_apply_kernel, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad, (double)count,
-                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
-                     (const float*)y, (const float*)res, (const float*)yr, scale_r, shift_r, relu, (float*)out, rows,
-                     rpb);
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad,
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                       (const float*)y, (const float*)res, (const float*)yr, scale_r, shift_r, relu, (float*)out, rows,
+                       rpb);
+  else
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad,
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                       (const bf16_t*)y, (const bf16_t*)res, (const bf16_t*)yr, scale_r, shift_r, relu, (bf16_t*)out,
+                       rows, rpb);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -198,11 +222,12 @@ int bn_finalize_apply_launch(const float* stats, int stat_rows, int C, int Cpad,
 // backward: partial sums of dz, dz * xhat -> (dgamma, dbeta, coefficients) ->
 //   dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)),  dz = dA * [a > 0]   (as bn_bwd_apply_kernel)
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     const float* __restrict__ partial, int nblocks, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, const float* __restrict__ dA,
-    const float* __restrict__ a, const float* __restrict__ y, float* __restrict__ dy, float* __restrict__ dres,
+    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, const T* __restrict__ dA,
+    const T* __restrict__ a, const T* __restrict__ y, T* __restrict__ dy, T* __restrict__ dres,
     int dres_acc, long rows, long rows_per_block, const float* __restrict__ mask_scale,
     const float* __restrict__ mask_shift) {
   __shared__ double red[16][64];
@@ -255,10 +280,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     for (int u = 0; u < U; ++u) {
       const long row = r + 32 * u;
       if (row < r1) {
-        g4[u] = *reinterpret_cast<const float4*>(dA + row * C + cc);
-        y4[u] = *reinterpret_cast<const float4*>(y + row * C + cc);
-        if (from_a) a4[u] = *reinterpret_cast<const float4*>(a + row * C + cc);
-        if (rd_dres) d4[u] = *reinterpret_cast<const float4*>(dres + row * C + cc);
+        g4[u] = ld4<T>(dA + row * C + cc);
+        y4[u] = ld4<T>(y + row * C + cc);
+        if (from_a) a4[u] = ld4<T>(a + row * C + cc);
+        if (rd_dres) d4[u] = ld4<T>(dres + row * C + cc);
       }
     }
 #pragma unroll
@@ -281,30 +306,37 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
         const float xhat = (yy[k] - mu[k]) * is[k];
         o[k] = k0[k] * (g[k] - k1[k] - xhat * k2[k]);
       }
-      *reinterpret_cast<float4*>(dy + row * C + cc) = make_float4(o[0], o[1], o[2], o[3]);
+      st4<T>(dy + row * C + cc, make_float4(o[0], o[1], o[2], o[3]));
       if (dres != nullptr) {
         if (dres_acc) {
           g[0] += d4[u].x; g[1] += d4[u].y; g[2] += d4[u].z; g[3] += d4[u].w;
         }
-        *reinterpret_cast<float4*>(dres + row * C + cc) = make_float4(g[0], g[1], g[2], g[3]);
+        st4<T>(dres + row * C + cc, make_float4(g[0], g[1], g[2], g[3]));
       }
     }
   }
 }
 
-int bn_bwd_finalize_apply_launch(const float* partial, int nblocks, int C, long count, const float* gamma,
+int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, int C, long count, const float* gamma,
                                  const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                  int accumulate, float* coef, const void* dA, const void* a, const void* y, void* dy,
                                  void* dres, int dres_acc, long rows, hipStream_t stream, const float* mask_scale,
                                  const float* mask_shift) {
-  D3F_CHECK(bn_fused_finalize_ok(D3F_F32, nblocks, C), "bn_bwd_finalize_apply: C=%d, %d partial rows", C, nblocks);
+  D3F_CHECK(bn_fused_finalize_ok(dtype, nblocks, C), "bn_bwd_finalize_apply: C=%d, %d partial rows", C, nblocks);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
   const long rpb = rows_per_block_for(rows, slabs);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
-  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, grid, dim3(256), 0, stream, partial, nblocks, C, (double)count,
-                     gamma, mean, invstd, dgamma, dbeta, accumulate, coef, (const float*)dA, (const float*)a,
-                     (const float*)y, (float*)dy, (float*)dres, dres_acc, rows, rpb, mask_scale, mask_shift);
+  if (dtype == D3F_F32)
+    hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, partial, nblocks, C,
+                       (double)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, (const float*)dA,
+                       (const float*)a, (const float*)y, (float*)dy, (float*)dres, dres_acc, rows, rpb, mask_scale,
+                       mask_shift);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, partial, nblocks, C,
+                       (double)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, (const bf16_t*)dA,
+                       (const bf16_t*)a, (const bf16_t*)y, (bf16_t*)dy, (bf16_t*)dres, dres_acc, rows, rpb, mask_scale,
+                       mask_shift);
   D3F_HIP(hipGetLastError());
   return 0;
 }

@@ -420,7 +420,9 @@ static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {
 size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d) {
   WgradParams w;
   if (wgrad_params(dtype, d, w) != 0) return 0;
-  return wgrad_partial_floats(w) * sizeof(float);
+  WgradLayer L;
+  if (wgrad_layer_plan(L, w, sdt(dtype)) != 0) return 0;
+  return std::max(wgrad_partial_floats(w), wgrad_layer_partial_floats(L)) * sizeof(float);
 }
 int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, const void* src0,
                              const void* src1, void* workspace, float* dw, void* stream) {
@@ -432,6 +434,13 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
     return 0;
   }
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
+  {  // the passes the engine runs for this layer (class form behind an up-sampling where it applies)
+    WgradLayer L;
+    if (int rc = wgrad_layer_plan(L, w, sdt(dtype))) return rc;
+    if (L.part[0].part != WG_WHOLE)
+      return wgrad_layer_launch(L, dy, src0, src1, reinterpret_cast<float*>(workspace), dw, d->Cout, d->CinReal, dtype,
+                                (hipStream_t)stream);
+  }
   w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
   if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
   WgradDst dst;

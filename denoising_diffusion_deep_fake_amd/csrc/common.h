@@ -190,7 +190,22 @@ struct WgradParams {
   int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
   int xcd_swizzle;  // tap-parallel kernel: XCD-aware workgroup order (filled by plan)
   double flops;  // algorithmic FLOPs of this launch, for profiling
+  // Which part of the layer's gradient this launch computes (set before wgrad_plan; everything below is filled by it):
+  //   WG_WHOLE  every input channel, KH*KW taps (the ordinary launch);
+  //   WG_CLASS  conv(cat(upsample2x(src0), src1)), channels of src0 only, in OUTPUT-PARITY-CLASS form: inside class
+  //             (py, px) the nine taps on the up-sampled operand touch a 2x2 neighbourhood of the low-resolution
+  //             src0, so the launch runs 4 classes x 2x2 = 16 "folded taps" over M/4 pixels each (4*M*C0 MACs per
+  //             filter instead of 9*M*C0) and the slab reduce adds the four folded taps every 3x3 tap belongs to;
+  //   WG_SKIP   the same layer's src1 channels, plain 3x3 (a launch over the ci tiles of the second source).
+  int part;
+  int cls;        // 1: class form (WG_CLASS)
+  int ci_base;    // first concatenated input channel of the launch (0, or C0 for WG_SKIP)
+  int slab_cin;   // input channels the launch covers = row width of its slabs
+  int slab_taps;  // taps per slab row block: KH*KW, or 16 folded taps
+  int Mi, Hc, Wc; // pixel grid the k-loop iterates: (M, Ho, Wo), or one parity class (M/4, H0s, W0s)
+  int step_img, step_row, step_col;  // one k-chunk (KP pixels) as whole images + rows + columns of that grid
 };
+enum WgradPart : int { WG_WHOLE = 0, WG_CLASS = 1, WG_SKIP = 2 };
 // Grouped launches: layers of identical shape (the 3x3 stride-1 convolutions inside one ResNet stage) run their
 // weight gradients as ONE launch, blockIdx.z = member.  With G members there are G times as many (tap, co, ci)
 // tiles to spread over the chip, so the pixel range is cut into G times fewer slabs: less partial-slab traffic,
@@ -214,5 +229,23 @@ int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hip
 // gradient [Cout][CinReal][KH][KW] (fp32), dropping padded channels; one launch for the whole group
 int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
                         int KH, int KW, const WgradDst& dst, hipStream_t stream);
+// the general form: the slabs cover `Cin` channels (`CinRealPart` of them real) that land at channel `c_off` of a
+// gradient with `CinRealTotal` input channels; fold != 0: slabs hold 16 folded taps per filter (WG_CLASS), summed
+// into the 3x3 taps they belong to
+int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
+                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
+                             hipStream_t stream);
+
+// The weight gradient of one convolution as 1 or 2 passes (launch + slab reduce each): a decoder layer behind an
+// up-sampling runs WG_CLASS + WG_SKIP when the tap-parallel kernel takes it, everything else WG_WHOLE.
+struct WgradLayer {
+  WgradParams part[2];
+  int nparts;
+};
+// base: geometry of the layer (B, Hv, Wv, C0, C1, H0s, W0s, shift0, Ho, Wo, Cout (padded), KH, KW, stride, pad, M, flops)
+int wgrad_layer_plan(WgradLayer& L, const WgradParams& base, int dtype);
+size_t wgrad_layer_partial_floats(const WgradLayer& L);  // slab scratch: the passes are stream-ordered, so the max
+int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
+                       float* dw, int CoutReal, int CinReal, int dtype, hipStream_t stream);
 
 }  // namespace d3f

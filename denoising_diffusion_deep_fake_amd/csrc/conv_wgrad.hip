@@ -64,9 +64,16 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // [32-channel subtile][32 pixels][32 channels] with 64-byte rows and the MFMA operands (8 consecutive k of one
 // channel per lane) are gathered with ds_read_b64_tr_b16, the hardware transposing read of gfx950: two reads
 // per fragment, conflict-free because the 4 rows x 64 B a half-wave touches are contiguous.
-template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3>
+//
+// CLS (WgradParams::cls): the class form of a layer behind a nearest x2 up-sampling, for the channels of the up-sampled
+// source.  blockIdx "tap" = one of 16 folded taps ((py, px) output-parity class x (a, b) position in the 2x2
+// neighbourhood); the k-loop runs over the LOW-resolution pixel grid (b, j, i): dY is read at (2j + py, 2i + px), the
+// source at (j + a - 1 + py, i + b - 1 + px) -- the low-resolution pixel under up-sampled row 2j + py + kh - 1 for the
+// taps kh that share `a` (kh = 0 | 1,2 for py = 0; kh = 0,1 | 2 for py = 1; columns alike).
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, const WgradGroup grp) {
   constexpr int VE = Elem<T>::VE;
+  static_assert(!CLS || BMW == BNW, "class form: dY and source rows share one pixel decode");
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
   constexpr int NPL = sizeof(T) == 4 ? 3 : 1;
@@ -109,9 +116,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   bid /= p.tiles_ci;
   const int tile_co = bid % p.tiles_co;
   const int tap = bid / p.tiles_co;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;
-  const int Cin = p.C0 + p.C1;
+  // plain: (kh, kw); class form: folded tap = ((py*2 + px)*2 + a)*2 + b -> dY at (2j + py, 2i + px), source pixel
+  // offset (a - 1 + py, b - 1 + px) on the low-resolution grid
+  const int kh = CLS ? ((tap >> 1) & 1) - 1 + (tap >> 3) : tap / p.KW;
+  const int kw = CLS ? (tap & 1) - 1 + ((tap >> 2) & 1) : tap - (tap / p.KW) * p.KW;
+  const int cpy = tap >> 3, cpx = (tap >> 2) & 1;  // class form only
+  const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;  // ci0: channel offset inside this launch's channel range
+  const int Cin = p.slab_cin;
 
   // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip); blockIdx.z = group member
   const void* const dy_ptr = grp.dy[member];
@@ -126,16 +137,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   constexpr int YRS = 256 / VY, XRS = 256 / VX;
   static_assert(256 % VY == 0 && 256 % VX == 0, "vector columns must divide the workgroup");
   const int yco = co0 + ycv * VE;
-  const int xci = ci0 + xcv * VE;
+  const int xci = p.ci_base + ci0 + xcv * VE;  // concatenated input channel
   const bool yvalid_c = yco < p.Cout;
-  const bool xvalid_c = xci < Cin;
-  const bool from0 = ci0 < p.C0;  // block-uniform: plan keeps ci tiles inside one source
+  const bool xvalid_c = ci0 + xcv * VE < Cin;
+  const bool from0 = CLS || (p.ci_base + ci0 < p.C0);  // block-uniform: plan keeps ci tiles inside one source
   const int xcl = from0 ? xci : xci - p.C0;
   const int Cs = from0 ? p.C0 : p.C1;
-  const int sh = from0 ? p.shift0 : 0;
+  const int sh = CLS ? 0 : (from0 ? p.shift0 : 0);  // class form reads the low-resolution source directly
   const int Hs = from0 ? p.H0s : p.Hv;
   const int Ws = from0 ? p.W0s : p.Wv;
-  const int HoWo = p.Ho * p.Wo;
+  const int HcWc = p.Hc * p.Wc;
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -147,70 +158,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
 
   const int chunk_begin = split * p.chunks_per_split;
   int chunk_end = chunk_begin + p.chunks_per_split;
-  const int total_chunks = (p.M + KP - 1) / KP;
+  const int total_chunks = (p.Mi + KP - 1) / KP;
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-  // incremental pixel decode (see load_chunk): valid when a 32-pixel step is a whole number of image
-  // rows (32 % Wo == 0, and rows-per-step <= Ho) or stays within at most one row wrap (Wo % 32 == 0)
-  const bool wo_ge = (p.Wo % KP) == 0;
-  const int rows_per_chunk = wo_ge ? 0 : KP / (p.Wo > 0 ? p.Wo : 1);
-  const bool incr = wo_ge || ((KP % p.Wo) == 0 && rows_per_chunk <= p.Ho);
+  // Incremental pixel decode: (b, oy, ox) of this thread's rows on the iterated grid (Hc x Wc per image), advanced by
+  // exactly one chunk = step_img images + step_row rows + step_col columns (computed on the host; at most one carry
+  // each since step_col < Wc and step_row < Hc) -- two integer divisions per row per chunk would cost ~100 VALU, and
+  // VALU time adds to the f32 MFMA time.
   int xb[NVX], xoy[NVX], xox[NVX];
 #pragma unroll
   for (int i = 0; i < NVX; ++i) {
     const int m = chunk_begin * KP + xrow0 + i * XRS;
-    const int b = m / HoWo;
-    const int r = m - b * HoWo;
+    const int b = m / HcWc;
+    const int r = m - b * HcWc;
     xb[i] = b;
-    xoy[i] = r / p.Wo;
-    xox[i] = r - xoy[i] * p.Wo;
+    xoy[i] = r / p.Wc;
+    xox[i] = r - xoy[i] * p.Wc;
   }
   uint4 ry[NVY], rx[NVX];
   auto load_chunk = [&](int ch) {
     const int pix0 = ch * KP;
-#pragma unroll
-    for (int i = 0; i < NVY; ++i) {
-      const int row = yrow0 + i * YRS;
-      const int m = pix0 + row;
-      const bool ok = yvalid_c && row < KP && m < p.M;
-      ry[i] = buf_load16(rdy, ok ? (unsigned)(m * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB);
-    }
-    unsigned off[NVX];
+    unsigned off[NVX], offy[NVY];
 #pragma unroll
     for (int i = 0; i < NVX; ++i) {
       const int row = xrow0 + i * XRS;
       const int m = pix0 + row;
-      int b, oy, ox;
-      if (incr) {
-        // (b, oy, ox) of this thread's row, advanced by exactly KP = 32 pixels per chunk: two integer
-        // divisions per row per chunk would cost ~100 VALU, and VALU time adds to the f32 MFMA time
-        b = xb[i]; oy = xoy[i]; ox = xox[i];
-        if (wo_ge) {            // Wo is a multiple of 32: at most one row wrap
-          int nx = ox + KP;
-          const int w = nx >= p.Wo ? 1 : 0;
-          nx -= w ? p.Wo : 0;
-          int ny = oy + w;
-          const int h = ny >= p.Ho ? 1 : 0;
-          ny = h ? 0 : ny;
-          xox[i] = nx; xoy[i] = ny; xb[i] = b + h;
-        } else {                // Wo divides 32: the column stays, rows advance by 32 / Wo
-          int ny = oy + rows_per_chunk;
-          const int h = ny >= p.Ho ? 1 : 0;
-          ny -= h ? p.Ho : 0;
-          xoy[i] = ny; xb[i] = b + h;
-        }
-      } else {
-        b = m / HoWo;
-        const int r = m - b * HoWo;
-        oy = r / p.Wo;
-        ox = r - oy * p.Wo;
+      const int b = xb[i], oy = xoy[i], ox = xox[i];
+      {
+        int nx = ox + p.step_col;
+        const int w = nx >= p.Wc ? 1 : 0;
+        nx -= w ? p.Wc : 0;
+        int ny = oy + p.step_row + w;
+        const int h = ny >= p.Hc ? 1 : 0;
+        ny -= h ? p.Hc : 0;
+        xox[i] = nx; xoy[i] = ny; xb[i] = b + p.step_img + h;
       }
-      const int iy = oy * p.stride - p.pad + kh;
-      const int ix = ox * p.stride - p.pad + kw;
-      const bool ok = xvalid_c && row < KP && m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+      const int iy = CLS ? oy + kh : oy * p.stride - p.pad + kh;
+      const int ix = CLS ? ox + kw : ox * p.stride - p.pad + kw;
+      const bool inb = CLS ? ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws)
+                           : ((unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv);
+      const bool ok = xvalid_c && row < KP && m < p.Mi && inb;
       const int pix = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
       off[i] = ok ? (unsigned)(pix * Cs + xcl) * (unsigned)sizeof(T) : BUF_OOB;
+      if constexpr (CLS) {  // dY row of the same pixel (BMW == BNW: identical loader roles)
+        const bool oky = yvalid_c && row < KP && m < p.Mi;
+        const int my = (b * p.Ho + 2 * oy + cpy) * p.Wo + 2 * ox + cpx;
+        offy[i] = oky ? (unsigned)(my * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB;
+      }
     }
+    if constexpr (!CLS) {
+#pragma unroll
+      for (int i = 0; i < NVY; ++i) {
+        const int row = yrow0 + i * YRS;
+        const int m = pix0 + row;
+        const bool ok = yvalid_c && row < KP && m < p.M;
+        offy[i] = ok ? (unsigned)(m * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) ry[i] = buf_load16(rdy, offy[i]);
     if (from0) {
 #pragma unroll
       for (int i = 0; i < NVX; ++i) rx[i] = buf_load16(rx0, off[i]);
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   }
 
   // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int taps = p.KH * p.KW;
+  const int taps = p.slab_taps;
   float* __restrict__ slab = p.partial + ((long)member * p.splits + split) * p.Cout * taps * Cin;
   if (KSPLIT > 1) {
     // the 4 waves hold partial sums of the same 32x32 tile: reduce through LDS
@@ -366,9 +372,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
 // summation tree, bitwise reproducible.  (Round 1's one-element-per-thread form read 4 bytes per lane, scattered
 // 4-byte stores `taps` floats apart and ran at 0.8 TB/s; a 64-filter layer with 114 slabs needs both the channel
 // chunks -- enough workgroups -- and the slab groups -- enough loads in flight.)
+//
+// Part form: the slabs cover `Cin` channels, `CinReal` of them real, that land at channel c_off of a gradient with
+// CinTot input channels.  FOLD: the slabs hold 16 folded taps per filter (WgradParams::cls); 3x3 tap (kh, kw) is the
+// sum over the four output-parity classes (py, px) of folded tap ((py*2 + px)*2 + a(py, kh))*2 + a(px, kw),
+// a(0, k) = k > 0, a(1, k) = k > 1 -- added in class order, a fixed tree.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int CoutP,
                                                            int Cin, int CinReal, int taps, int CB, int nsg, int VB,
-                                                           const WgradDst dst) {
+                                                           const WgradDst dst, int CinTot, int c_off) {
   extern __shared__ __attribute__((aligned(16))) float row[];  // [nsg][taps][CB + 1]
   const int co = blockIdx.x, member = blockIdx.y, c0 = blockIdx.z * CB;
   const int rowlen = taps * Cin;
@@ -408,12 +420,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   __syncthreads();
   const int creal = min(CB, CinReal - c0);  // <= 0 for a chunk of padding channels only
-  float* __restrict__ out = dst.dw[member] + ((long)co * CinReal + c0) * taps;
-  for (int o = threadIdx.x; o < creal * taps; o += 256) {
-    const int ci = o / taps, tap = o - ci * taps;
-    float s = row[tap * LR + ci];
-    for (int g = 1; g < nsg; ++g) s += row[g * plane + tap * LR + ci];
-    out[o] = s;
+  if constexpr (FOLD) {
+    float* __restrict__ out = dst.dw[member] + ((long)co * CinTot + c_off + c0) * 9;
+    for (int o = threadIdx.x; o < creal * 9; o += 256) {
+      const int ci = o / 9, t9 = o - ci * 9, kh = t9 / 3, kw = t9 - kh * 3;
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int a = py ? (kh > 1) : (kh > 0), b = px ? (kw > 1) : (kw > 0);
+        const int tap = ((c * 2) + a) * 2 + b;
+        float sc = row[tap * LR + ci];
+        for (int g = 1; g < nsg; ++g) sc += row[g * plane + tap * LR + ci];
+        s += sc;
+      }
+      out[o] = s;
+    }
+  } else {
+    float* __restrict__ out = dst.dw[member] + ((long)co * CinTot + c_off + c0) * taps;
+    for (int o = threadIdx.x; o < creal * taps; o += 256) {
+      const int ci = o / taps, tap = o - ci * taps;
+      float s = row[tap * LR + ci];
+      for (int g = 1; g < nsg; ++g) s += row[g * plane + tap * LR + ci];
+      out[o] = s;
+    }
   }
 }
 
@@ -436,6 +466,17 @@ int wgrad_patch_variant(const WgradParams& p, int dtype);
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy);
 int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t stream);
 
+// Does the weight gradient of conv(cat(upsample2x(src0), src1)) run as WG_CLASS + WG_SKIP passes?  The tap-parallel
+// kernel's 64x64 tile only (the narrow decoder layers keep the persistent patch kernel); C0 a whole number of ci tiles.
+bool wgrad_class_applies(const WgradParams& p, int dtype) {
+  static const bool off = getenv("D3F_NO_WGRAD_CLASS") != nullptr;  // debugging knob: nine taps through the up-sampling
+  if (off || !p.shift0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
+  if (p.Ho != p.Hv || p.Wo != p.Wv || p.H0s * 2 != p.Hv || p.W0s * 2 != p.Wv) return false;
+  if (getenv("D3F_NO_PATCH_WGRAD") == nullptr && wgrad_patch_variant(p, dtype)) return false;
+  const WTile t = pick_wtile(p);
+  return t.bm == 64 && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
+}
+
 int wgrad_plan(WgradParams& p, int dtype, int group) {
   D3F_CHECK(group >= 1 && group <= WG_MAXG, "wgrad: group of %d layers", group);
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "wgrad: bad dtype %d", dtype);
@@ -445,13 +486,27 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
             "wgrad: channels (%d,%d,%d) must be multiples of %d", p.C0, p.C1, p.Cout, ve);
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
+  D3F_CHECK(p.part == WG_WHOLE || p.part == WG_CLASS || p.part == WG_SKIP, "wgrad: part %d", p.part);
   const WTile t = pick_wtile(p);
   D3F_CHECK(p.C1 == 0 || (p.C0 % t.bn) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t.bn);
   const long bdy = (long)p.M * p.Cout * es, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es,
              b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
   D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
   p.dy_bytes = (unsigned)bdy; p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1;
-  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
+  // the part of the layer this launch covers
+  p.cls = p.part == WG_CLASS ? 1 : 0;
+  p.ci_base = p.part == WG_SKIP ? p.C0 : 0;
+  p.slab_cin = p.part == WG_CLASS ? p.C0 : p.part == WG_SKIP ? p.C1 : p.C0 + p.C1;
+  p.slab_taps = p.cls ? 16 : p.KH * p.KW;
+  p.Hc = p.cls ? p.H0s : p.Ho;
+  p.Wc = p.cls ? p.W0s : p.Wo;
+  p.Mi = p.B * p.Hc * p.Wc;
+  if (p.part != WG_WHOLE) {
+    D3F_CHECK(group == 1 && wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
+    p.patch = 0;
+  } else {
+    p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
+  }
   D3F_CHECK(group == 1 || (p.patch == 0 && p.C1 == 0), "wgrad: only plain single-source layers are grouped");
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
     int gx, gy;
@@ -461,11 +516,16 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
     p.tiles_co = p.tiles_ci = 0;
     return 0;
   }
-  const int cin = p.C0 + p.C1;
+  {  // one k-chunk (KP pixels) in units of the iterated grid
+    const int hw = p.Hc * p.Wc, rem = KP % hw;
+    p.step_img = KP / hw;
+    p.step_row = rem / p.Wc;
+    p.step_col = rem % p.Wc;
+  }
   p.tiles_co = cdiv(p.Cout, t.bm);
-  p.tiles_ci = cdiv(cin, t.bn);
-  const long base = (long)p.tiles_co * p.tiles_ci * p.KH * p.KW * group;
-  const int total_chunks = cdiv(p.M, KP);
+  p.tiles_ci = cdiv(p.slab_cin, t.bn);
+  const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps * group;
+  const int total_chunks = cdiv(p.Mi, KP);
   long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
   if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
   long splits = (target + base - 1) / base;
@@ -480,7 +540,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
 }
 
 size_t wgrad_partial_floats(const WgradParams& p) {
-  return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+  if (p.patch) return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
+  return (size_t)p.splits * p.Cout * p.slab_taps * p.slab_cin;
 }
 
 template <typename T>
@@ -495,10 +556,12 @@ static void wgrad_launch_t(const WgradParams& p, const WgradGroup& g, int bm, di
   } else if (bm == 64) {
     static const bool widen = getenv("D3F_BF16_WGRAD_F32") != nullptr;  // bf16 storage: old widening form (tuning knob)
     if (x3 || (sizeof(T) == 2 && !widen)) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, lds_pad, stream, p, g);
+      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, true>), grid, block, lds_pad, stream, p, g);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, lds_pad, stream, p, g);
       return;
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
+    if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true>), grid, block, lds_pad, stream, p, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, lds_pad, stream, p, g);
   }
@@ -525,8 +588,10 @@ int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hip
     return rc;
   }
   const WTile t = pick_wtile(p);
-  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1, "wgrad: params were not planned");
-  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.KH * p.KW), (unsigned)p.splits, (unsigned)g.n);
+  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1,
+            "wgrad: params were not planned");
+  D3F_CHECK(!p.cls || t.bm == 64, "wgrad: class form needs the 64x64 tile");
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits, (unsigned)g.n);
   const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops * g.n, stream);
   if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, g, t.bm, grid, stream, false);
@@ -538,8 +603,16 @@ int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hip
 
 int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
                         int KH, int KW, const WgradDst& dst, hipStream_t stream) {
-  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG && Cin % 4 == 0 && CinReal <= Cin && Cout <= CoutP, "wgrad reduce: arguments");
-  const int taps = KH * KW;
+  return wgrad_reduce_launch_part(partial, splits, CoutP, Cout, Cin, CinReal, CinReal, 0, KH, KW, 0, dst, stream);
+}
+
+int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
+                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
+                             hipStream_t stream) {
+  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG && Cin % 4 == 0 && CinRealPart <= Cin && Cout <= CoutP &&
+                c_off + CinRealPart <= CinRealTotal && (!fold || (KH == 3 && KW == 3)),
+            "wgrad reduce: arguments");
+  const int taps = fold ? 16 : KH * KW;
   int cz = 1;  // channel chunks: enough workgroups to fill the chip, chunks of at least 16 channels (64-byte segments)
   while ((long)Cout * dst.n * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
   const int CB = Cin / cz, nvec = taps * CB / 4;
@@ -549,9 +622,59 @@ int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, i
   const int VB = nsg == 1 ? 256 : (nvec < 256 / nsg ? nvec : 256 / nsg);
   const size_t lds = (size_t)nsg * taps * (CB + 1) * sizeof(float);
   D3F_CHECK(lds <= 64 * 1024, "wgrad reduce: a %d-tap x %d-channel filter chunk exceeds the LDS tile", taps, CB);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)dst.n, (unsigned)cz), dim3(256), lds, stream,
-                     partial, splits, CoutP, Cin, CinReal, taps, CB, nsg, VB, dst);
+  const dim3 grid((unsigned)Cout, (unsigned)dst.n, (unsigned)cz);
+  if (fold)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, grid, dim3(256), lds, stream, partial, splits, CoutP, Cin, CinRealPart,
+                       taps, CB, nsg, VB, dst, CinRealTotal, c_off);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, grid, dim3(256), lds, stream, partial, splits, CoutP, Cin, CinRealPart,
+                       taps, CB, nsg, VB, dst, CinRealTotal, c_off);
   D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- a layer's weight gradient as 1 or 2 passes -----------------------------------------------------------------
+int wgrad_layer_plan(WgradLayer& L, const WgradParams& base, int dtype) {
+  L.nparts = 1;
+  L.part[0] = base;
+  L.part[0].part = WG_WHOLE;
+  if (wgrad_class_applies(base, dtype)) {
+    L.part[0].part = WG_CLASS;
+    L.part[0].flops = base.flops * base.C0 / (base.C0 + base.C1);  // algorithmic credit: the original nine taps
+    if (base.C1 > 0) {
+      L.nparts = 2;
+      L.part[1] = base;
+      L.part[1].part = WG_SKIP;
+      L.part[1].flops = base.flops * base.C1 / (base.C0 + base.C1);
+    }
+  }
+  for (int i = 0; i < L.nparts; ++i)
+    if (int rc = wgrad_plan(L.part[i], dtype, 1)) return rc;
+  return 0;
+}
+
+size_t wgrad_layer_partial_floats(const WgradLayer& L) {
+  size_t n = 0;
+  for (int i = 0; i < L.nparts; ++i) n = std::max(n, wgrad_partial_floats(L.part[i]));
+  return n;
+}
+
+int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
+                       float* dw, int CoutReal, int CinReal, int dtype, hipStream_t stream) {
+  WgradDst dst;
+  dst.n = 1;
+  dst.dw[0] = dw;
+  for (int i = 0; i < L.nparts; ++i) {
+    WgradParams w = L.part[i];
+    w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = partial;
+    if (int rc = wgrad_launch(w, dtype, stream)) return rc;
+    const int c_off = w.ci_base;
+    // real channels of this part: channel padding only ever sits at the end of the concatenation
+    const int creal = std::max(0, std::min(w.slab_cin, CinReal - c_off));
+    if (int rc = wgrad_reduce_launch_part(partial, w.splits, w.Cout, CoutReal, w.patch ? w.C0 + w.C1 : w.slab_cin, creal,
+                                          CinReal, c_off, w.KH, w.KW, w.cls, dst, stream))
+      return rc;
+  }
   return 0;
 }
 

@@ -204,6 +204,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 
 // variants: 1: 3x3 s1, <=16 out, 32-channel slices (decoder 4 conv1)   2: 3x3 s1, <=16 out, 16-channel slices
 //           3: 3x3 s1, 32-out slices, 32-channel slices (decoder 3)     4: 7x7 s2 stem, 4 (3+pad) channels
+//           5: 7x7 s2 stem in bf16 storage, 8 (3+pad) channels (the tap-parallel kernel took 725 us for this
+//              layer -- 49 taps x 2 filter tiles re-reading the 128x128 dY 49 times -- and sat at the very end of the
+//              weight-gradient stream: profiles/r03_bf16_step_timeline.txt)
 int wgrad_patch_variant(const WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   if (p.KH != p.KW) return 0;
@@ -214,14 +217,17 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
   }
   if (dtype == D3F_F32 && p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 4 && p.C1 == 0 &&
       p.Cout % 32 == 0 && p.Cout <= 64)
-    return 4;  // f32 only: bf16 pads the stem input to 8 channels
+    return 4;  // f32: 3 channels padded to 4
+  if (dtype == D3F_BF16 && p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 8 && p.C1 == 0 &&
+      p.Cout % 32 == 0 && p.Cout <= 64)
+    return 5;  // bf16 pads the stem input to 8 channels (one 16-byte vector per pixel)
   return 0;
 }
 
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   const int cin = p.C0 + p.C1;
-  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : 4;
-  const int co_t = (variant == 3 || variant == 4) ? 32 : 16;
+  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : variant == 5 ? 8 : 4;
+  const int co_t = (variant == 3 || variant == 4 || variant == 5) ? 32 : 16;
   const int slices = (cin / ci_t) * cdiv(p.Cout, co_t);
   const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
   int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
@@ -248,8 +254,11 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
   D3F_CHECK(p.splits == gx, "wgrad patch: params were not planned (splits %d vs %d)", p.splits, gx);
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (variant == 4) {
-    D3F_CHECK(dtype == D3F_F32, "wgrad patch: the stem variant is f32 only");
+    D3F_CHECK(dtype == D3F_F32, "wgrad patch: stem variant 4 is the f32 one");
     hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
+  } else if (variant == 5) {
+    D3F_CHECK(dtype == D3F_BF16, "wgrad patch: stem variant 5 is the bf16 one");
+    hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 8, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (dtype == D3F_F32) {
     if (int rc = patch_launch_t<float>(p, variant, grid, stream)) return rc;
   } else {

@@ -55,6 +55,10 @@ struct Unit {
   int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)
   ConvParams fwd{}, dgrad{};
   WgradParams wg{};
+  // weight gradient as WG_CLASS + WG_SKIP passes (conv_wgrad.hip): the decoder layers behind an up-sampling whose
+  // gradient runs on the tap-parallel kernel -- 4/9 of the MACs on the up-sampled channels
+  bool wclass = false;
+  WgradLayer wl{};
   int Cin() const { return C0 + C1; }
 };
 

@@ -197,6 +197,15 @@ int UnetEngine::plan_unit(Unit& u) {
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = (int)rows_full;
   g.flops = 2.0 * macs;
+  {
+    const WgradParams base = g;
+    if (int rc = wgrad_layer_plan(u.wl, base, dtype)) return rc;
+    u.wclass = u.wl.part[0].part != WG_WHOLE;
+    if (u.wclass) {
+      const size_t wb = wgrad_layer_partial_floats(u.wl) * sizeof(float);
+      if (wb > wpart_bytes) wpart_bytes = wb;
+    }
+  }
   if (int rc = wgrad_plan(g, dtype)) return rc;  // single-layer plan; identical layers are re-planned as a group in build()
   {
     const size_t wb = wgrad_partial_floats(g) * sizeof(float);
@@ -423,7 +432,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   // gradient also emits the (dbeta, dgamma) partial sums of the unit that consumes it -- when that unit is the very
   // next op (bnpart is one stream-ordered scratch).  The producer may accumulate (it sums first, then reduces the
   // final values); a consumer with a residual add takes its ReLU mask from its activation instead of from y.
-  if (dtype == D3F_F32 && getenv("D3F_NO_FUSED_BN_REDUCE") == nullptr) {
+  if (getenv("D3F_NO_FUSED_BN_REDUCE") == nullptr) {
     auto writes = [&](const BwdOp& o, int gid) {
       if (o.kind == BW_UNIT || o.kind == BW_HEAD) {
         if (units[o.unit].need_dgrad && !o.dst0_is_full_scratch && o.dst0 == gid) return true;
@@ -715,7 +724,7 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       const long rows = (long)B * u.Ho * u.Wo;  // (p.M counts one output-parity class for a folded layer)
       if (u.apply && bn_fused_finalize_ok(dtype, p.stat_rows, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip): one launch instead of two
-        if (int rc = bn_finalize_apply_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, rows, params_ + u.g_off,
+        if (int rc = bn_finalize_apply_launch(dtype, p.stats, p.stat_rows, u.Cout, u.CoutPad, rows, params_ + u.g_off,
                                               params_ + u.b_off, 1e-5f, 0.1f, bnstats + u.rm_off, bnstats + u.rv_off,
                                               coef_ptr(ws, u, 0), coef_ptr(ws, u, 1), coef_ptr(ws, u, 2),
                                               coef_ptr(ws, u, 3), T(u.y),
@@ -942,6 +951,12 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
     for (int ui : pending) {
       const Unit& u = units[ui];
+      if (u.wclass) {  // class-form passes of a layer behind an up-sampling (never grouped)
+        if (int rc = wgrad_layer_launch(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr, wpart,
+                                        grads + u.w_off, u.Cout, u.CinReal, cdtype, ws_stream))
+          return rc;
+        continue;
+      }
       const WGroup& grp = wgroups[u.wgroup];
       WgradParams g = grp.wg;
       WgradGroup gp;
@@ -1001,9 +1016,11 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       float* invstd = coef_ptr(ws, u, 1);
       float* k = coef_ptr(ws, u, 4);
       float* bnpart = reinterpret_cast<float*>(ws + bnpart_off);
-      // ReLU mask: layers without a residual recompute it from y (f32: bit-identical to a > 0, since the
-      // forward apply used the same y*scale + shift); residual layers and bf16 read the saved activation
-      const bool from_y = op.mask && dtype == D3F_F32 && u.res_tensor < 0 && u.res_unit < 0;
+      // ReLU mask: layers without a residual recompute it from y (identical to a > 0: the forward apply used the
+      // same fp32 y*scale + shift on the same stored y, and rounding a positive fp32 value to bf16 never gives
+      // zero); residual layers read the saved activation
+      static const bool bf16_mask_from_a = getenv("D3F_BF16_MASK_FROM_A") != nullptr;  // debugging knob
+      const bool from_y = op.mask && (dtype == D3F_F32 || !bf16_mask_from_a) && u.res_tensor < 0 && u.res_unit < 0;
       const void* amask = (op.mask && !from_y) ? T(u.a) : nullptr;
       const float* msc = from_y ? coef_ptr(ws, u, 2) : nullptr;
       const float* msf = from_y ? coef_ptr(ws, u, 3) : nullptr;
@@ -1017,7 +1034,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       }
       if (!skip_b && bn_fused_finalize_ok(dtype, nb, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip)
-        if (int rc = bn_bwd_finalize_apply_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,
+        if (int rc = bn_bwd_finalize_apply_launch(dtype, bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,
                                                   grads + u.g_off, grads + u.b_off, 0, k, G(op.dA), amask, T(u.y), dy,
                                                   op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows, s,
                                                   msc, msf))

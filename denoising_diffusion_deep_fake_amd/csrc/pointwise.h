@@ -51,12 +51,12 @@ int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y,
 
 // bn_fused.hip: the finalize step folded into the streaming pass (fp32 tensors, C % 32 == 0, few partial rows)
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C);
-int bn_finalize_apply_launch(const float* stats, int stat_rows, int C, int Cpad, long count, const float* gamma,
+int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C, int Cpad, long count, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, float* scale, float* shift,
                              const void* y, const void* res, const void* yr, const float* scale_r,
                              const float* shift_r, int relu, void* out, long rows, hipStream_t stream);
-int bn_bwd_finalize_apply_launch(const float* partial, int nblocks, int C, long count, const float* gamma,
+int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, int C, long count, const float* gamma,
                                  const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                  int accumulate, float* coef, const void* dA, const void* a, const void* y, void* dy,
                                  void* dres, int dres_acc, long rows, hipStream_t stream,
