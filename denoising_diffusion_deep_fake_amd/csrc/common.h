@@ -203,7 +203,8 @@ struct WgradParams {
   int slab_cin;   // input channels the launch covers = row width of its slabs
   int slab_taps;  // taps per slab row block: KH*KW, or 16 folded taps
   int Mi, Hc, Wc; // pixel grid the k-loop iterates: (M, Ho, Wo), or one parity class (M/4, H0s, W0s)
-  int step_img, step_row, step_col;  // one k-chunk (KP pixels) as whole images + rows + columns of that grid
+  int step_img, step_row, step_col;  // one k-chunk (kp pixels) as whole images + rows + columns of that grid
+  int kp;         // pixels per k-chunk of the chosen kernel form: 32, or 128 for the slim 32x32 k-split tile
 };
 enum WgradPart : int { WG_WHOLE = 0, WG_CLASS = 1, WG_SKIP = 2 };
 // Grouped launches: layers of identical shape (the 3x3 stride-1 convolutions inside one ResNet stage) run their

@@ -21,7 +21,7 @@
 
 namespace d3f {
 
-constexpr int KP = 32;  // pixels per k-chunk
+constexpr int KP = 32;  // pixels per k-chunk (the kernel's KPX; WgradParams::kp carries the launch's value)
 
 // store one 16-byte global vector (4 f32 or 8 bf16) as f32 into LDS
 template <typename T> __device__ __forceinline__ void lds_store_as_f32(float* dst, const uint4& v);
@@ -70,9 +70,16 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // neighbourhood); the k-loop runs over the LOW-resolution pixel grid (b, j, i): dY is read at (2j + py, 2i + px), the
 // source at (j + a - 1 + py, i + b - 1 + px) -- the low-resolution pixel under up-sampled row 2j + py + kh - 1 for the
 // taps kh that share `a` (kh = 0 | 1,2 for py = 0; kh = 0,1 | 2 for py = 1; columns alike).
-template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false>
+//
+// KPX: pixels per k-chunk.  32 everywhere except the "slim" form of the wide layers (32x32 tile, the four waves
+// splitting each 128-pixel chunk): per workgroup it writes a 4 KB slab instead of the 64x64 tile's 16 KB, so at the
+// same workgroup count the slab traffic (and the reduce pass that re-reads it) is a quarter, for twice the L2 -> LDS
+// staging per MFMA; 16 MFMAs per wave between barriers in both forms.
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false, int KPX = 32>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, const WgradGroup grp) {
   constexpr int VE = Elem<T>::VE;
+  constexpr int KP = KPX;  // shadows the namespace constant: everything below counts in this kernel's chunk
+  static_assert(!X3 || KPX == 32, "x3 staging is laid out for 32-pixel chunks");
   static_assert(!CLS || BMW == BNW, "class form: dY and source rows share one pixel decode");
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
@@ -448,18 +455,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WTile {
-  int bm, bn;
+  int bm, bn, kp;
 };
-static WTile pick_wtile(const WgradParams& p) {
+static WTile pick_wtile(const WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   if (const char* f = getenv("D3F_WGRAD_TILE")) {  // tuning knob
     const int t = atoi(f);
-    if ((t == 128 || t == 64 || t == 32) && (p.C1 == 0 || p.C0 % t == 0)) return {t, t};
+    if ((t == 128 || t == 64 || t == 32) && (p.C1 == 0 || p.C0 % t == 0)) return {t, t, 32};
   }
   // measured per layer of Unet(resnet34) at B=16, 256x256 (profiles/README.md, r01_h): with ~1024 blocks the
   // 64x64 tile beats 128x128 on every wide layer (fewer split slabs to write and re-read), by 15-20%
-  if (p.Cout > 32 && cin > 32) return {64, 64};
-  return {32, 32};
+  if (p.Cout > 32 && cin > 32) {
+    // slim form (fp32 storage): 32x32 tile, 128-pixel chunks split over the four waves -- a quarter of the slab bytes.
+    // D3F_WGRAD_SLIM=<min channels>: layers with at least that many filters take it (0 / unset: none)
+    static const int slim_from = getenv("D3F_WGRAD_SLIM") ? atoi(getenv("D3F_WGRAD_SLIM")) : 0;
+    if (dtype == D3F_F32 && slim_from > 0 && p.Cout >= slim_from && (p.C1 == 0 || p.C0 % 32 == 0)) return {32, 32, 128};
+    return {64, 64, 32};
+  }
+  return {32, 32, 32};
 }
 
 int wgrad_patch_variant(const WgradParams& p, int dtype);
@@ -473,8 +486,8 @@ bool wgrad_class_applies(const WgradParams& p, int dtype) {
   if (off || !p.shift0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
   if (p.Ho != p.Hv || p.Wo != p.Wv || p.H0s * 2 != p.Hv || p.W0s * 2 != p.Wv) return false;
   if (getenv("D3F_NO_PATCH_WGRAD") == nullptr && wgrad_patch_variant(p, dtype)) return false;
-  const WTile t = pick_wtile(p);
-  return t.bm == 64 && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
+  const WTile t = pick_wtile(p, dtype);
+  return (t.bm == 64 || t.kp == 128) && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
 }
 
 int wgrad_plan(WgradParams& p, int dtype, int group) {
@@ -487,7 +500,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
   D3F_CHECK(p.part == WG_WHOLE || p.part == WG_CLASS || p.part == WG_SKIP, "wgrad: part %d", p.part);
-  const WTile t = pick_wtile(p);
+  const WTile t = pick_wtile(p, dtype);
+  p.kp = t.kp;
   D3F_CHECK(p.C1 == 0 || (p.C0 % t.bn) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t.bn);
   const long bdy = (long)p.M * p.Cout * es, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es,
              b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
@@ -516,16 +530,16 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
     p.tiles_co = p.tiles_ci = 0;
     return 0;
   }
-  {  // one k-chunk (KP pixels) in units of the iterated grid
-    const int hw = p.Hc * p.Wc, rem = KP % hw;
-    p.step_img = KP / hw;
+  {  // one k-chunk (kp pixels) in units of the iterated grid
+    const int hw = p.Hc * p.Wc, rem = p.kp % hw;
+    p.step_img = p.kp / hw;
     p.step_row = rem / p.Wc;
     p.step_col = rem % p.Wc;
   }
   p.tiles_co = cdiv(p.Cout, t.bm);
   p.tiles_ci = cdiv(p.slab_cin, t.bn);
   const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps * group;
-  const int total_chunks = cdiv(p.Mi, KP);
+  const int total_chunks = cdiv(p.Mi, p.kp);
   long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
   if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
   long splits = (target + base - 1) / base;
@@ -562,6 +576,11 @@ static void wgrad_launch_t(const WgradParams& p, const WgradGroup& g, int bm, di
     }
     if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true>), grid, block, lds_pad, stream, p, g);
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
+  } else if (p.kp == 128) {
+    if constexpr (sizeof(T) == 4) {
+      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false, true, 128>), grid, block, lds_pad, stream, p, g);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false, false, 128>), grid, block, lds_pad, stream, p, g);
+    }
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, lds_pad, stream, p, g);
   }
@@ -587,10 +606,12 @@ int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hip
     if (prof) prof_end(stream);
     return rc;
   }
-  const WTile t = pick_wtile(p);
-  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1,
+  const WTile t = pick_wtile(p, dtype == D3F_F32X3 ? D3F_F32 : dtype);
+  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1 && p.kp == t.kp,
             "wgrad: params were not planned");
-  D3F_CHECK(!p.cls || t.bm == 64, "wgrad: class form needs the 64x64 tile");
+  D3F_CHECK(!p.cls || t.bm == 64 || t.kp == 128, "wgrad: class form needs the 64x64 or the slim tile");
+  // (like the patch kernels, the slim tile stays on the fp32 MFMA in f32x3 mode)
+  D3F_CHECK(t.kp == 32 || dtype != D3F_BF16, "wgrad: the slim tile is an fp32-storage form");
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits, (unsigned)g.n);
   const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops * g.n, stream);
