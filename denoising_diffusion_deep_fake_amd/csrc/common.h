@@ -65,6 +65,12 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// the same with a wave-uniform byte offset added by the instruction (soffset): one address register serves several loads
+__device__ __forceinline__ uint4 buf_load16s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned soff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;    // elements per 16-byte vector

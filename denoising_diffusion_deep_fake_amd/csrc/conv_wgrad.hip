@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   constexpr int VE = Elem<T>::VE;
   constexpr int KP = KPX;  // shadows the namespace constant: everything below counts in this kernel's chunk
   static_assert(!X3 || KPX == 32, "x3 staging is laid out for 32-pixel chunks");
-  static_assert(!CLS || BMW == BNW, "class form: dY and source rows share one pixel decode");
+
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
   constexpr int NPL = sizeof(T) == 4 ? 3 : 1;
   constexpr int TM = BMW / WGM, TN = BNW / WGN, FM = TM / 32, FN = TN / 32;
   constexpr int LY = BMW + 4, LX = BNW + 4;    // LDS row strides (floats), 16-B aligned rows
   constexpr int VY = BMW / VE, VX = BNW / VE;  // 16-byte global vectors per row
-  constexpr int NVY = (KP * VY + 255) / 256, NVX = (KP * VX + 255) / 256;
+  constexpr int NVY = (VY * KP + 255) / 256, NVX = (VX * KP + 255) / 256;  // 16-byte vectors per thread: its row's columns lcol + j * (256 / KP)
   static_assert(WGM * WGN * KSPLIT == 4, "4 waves");
   constexpr int RED = (KSPLIT > 1) ? KSPLIT * 32 * 32 : 1;
   // x3: per operand 3 planes x 2 subtiles x [32 pixels][32 channels] bf16
@@ -138,15 +138,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(src0_ptr, p.src0_bytes);
   const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : src0_ptr, p.src1_bytes);
 
-  // loader roles: vector id = tid + i*256 -> (row, vector column)
-  const int ycv = tid % VY, yrow0 = tid / VY;  // rows yrow0 + i*YRS
-  const int xcv = tid % VX, xrow0 = tid / VX;
-  constexpr int YRS = 256 / VY, XRS = 256 / VX;
-  static_assert(256 % VY == 0 && 256 % VX == 0, "vector columns must divide the workgroup");
-  const int yco = co0 + ycv * VE;
-  const int xci = p.ci_base + ci0 + xcv * VE;  // concatenated input channel
-  const bool yvalid_c = yco < p.Cout;
-  const bool xvalid_c = ci0 + xcv * VE < Cin;
+  // loader roles: every thread owns ONE pixel row of the chunk (lrow) and the 16-byte vectors lcol + j * TPR of it, in
+  // both operands -- one pixel decode and one validity test per thread and chunk serve all of its loads.  (On gfx950
+  // the fp32 MFMA and the vector ALU of a SIMD exclude each other ACROSS waves, profiles/microbench/mfma_valu_corun.hip:
+  // every VALU cycle of the loader is a cycle no wave of the SIMD can spend in the matrix pipe.)
+  constexpr int TPR = 256 / KP;  // threads per pixel row
+  static_assert(256 % KP == 0, "whole threads per pixel row");
+  const int lrow = tid / TPR, lcol = tid % TPR;
+  const int yco = co0 + lcol * VE;                 // first of this thread's output channels (vector j: + j * TPR * VE)
+  const int xci = p.ci_base + ci0 + lcol * VE;     // concatenated input channel of vector 0
   const bool from0 = CLS || (p.ci_base + ci0 < p.C0);  // block-uniform: plan keeps ci tiles inside one source
   const int xcl = from0 ? xci : xci - p.C0;
   const int Cs = from0 ? p.C0 : p.C1;
@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   const int Hs = from0 ? p.H0s : p.Hv;
   const int Ws = from0 ? p.W0s : p.Wv;
   const int HcWc = p.Hc * p.Wc;
+  // LIN: the source pixel of output pixel m at this tap is m + a constant (stride 1, 'same' extent, source read at its
+  // own resolution -- every layer but the stride-2 ones and the class form by construction): the byte offset then
+  // advances by a constant per chunk, the pixel decode is only needed for the border test
+  const bool lin = CLS || (p.stride == 1 && p.Ho == p.Hv && p.Wo == p.Wv && sh == 0);
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -168,68 +172,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   const int total_chunks = (p.Mi + KP - 1) / KP;
   if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-  // Incremental pixel decode: (b, oy, ox) of this thread's rows on the iterated grid (Hc x Wc per image), advanced by
+  // Incremental pixel decode: (b, oy, ox) of this thread's row on the iterated grid (Hc x Wc per image), advanced by
   // exactly one chunk = step_img images + step_row rows + step_col columns (computed on the host; at most one carry
-  // each since step_col < Wc and step_row < Hc) -- two integer divisions per row per chunk would cost ~100 VALU, and
-  // VALU time adds to the f32 MFMA time.
-  int xb[NVX], xoy[NVX], xox[NVX];
-#pragma unroll
-  for (int i = 0; i < NVX; ++i) {
-    const int m = chunk_begin * KP + xrow0 + i * XRS;
-    const int b = m / HcWc;
-    const int r = m - b * HcWc;
-    xb[i] = b;
-    xoy[i] = r / p.Wc;
-    xox[i] = r - xoy[i] * p.Wc;
+  // each since step_col < Wc and step_row < Hc) -- two integer divisions per chunk would cost ~100 VALU.
+  int xb, xoy, xox;
+  {
+    const int m = chunk_begin * KP + lrow;
+    xb = m / HcWc;
+    const int r = m - xb * HcWc;
+    xoy = r / p.Wc;
+    xox = r - xoy * p.Wc;
   }
+  // taps as pixel offsets on the grid the source is addressed on
+  const int dkh = CLS ? kh : kh - p.pad, dkw = CLS ? kw : kw - p.pad;
+  // running byte offsets of vector 0 of this thread's row (valid or not; selected against BUF_OOB per chunk)
+  unsigned yoff = CLS ? (unsigned)((4 * (chunk_begin * KP + lrow) + 2 * cpy * p.Wc + cpx) * p.Cout + yco) * (unsigned)sizeof(T)
+                      : (unsigned)((chunk_begin * KP + lrow) * p.Cout + yco) * (unsigned)sizeof(T);
+  const unsigned ystep = (unsigned)((CLS ? 4 : 1) * KP * p.Cout) * (unsigned)sizeof(T);
+  const unsigned yox2 = (unsigned)(2 * p.Cout) * (unsigned)sizeof(T);  // class form: dY pixel = 4 m - 2 ox + const
+  unsigned xoff = (unsigned)((chunk_begin * KP + lrow + dkh * Ws + dkw) * Cs + xcl) * (unsigned)sizeof(T);  // LIN only
+  const unsigned xstep = (unsigned)(KP * Cs) * (unsigned)sizeof(T);
+  constexpr unsigned VSTEP = TPR * VE * sizeof(T);  // bytes between a thread's vectors of one row
+  bool ycol[NVY], xcol[NVX];
+#pragma unroll
+  for (int j = 0; j < NVY; ++j) ycol[j] = lcol + j * TPR < VY && yco + j * TPR * VE < p.Cout;
+#pragma unroll
+  for (int j = 0; j < NVX; ++j) xcol[j] = lcol + j * TPR < VX && ci0 + (lcol + j * TPR) * VE < Cin;
   uint4 ry[NVY], rx[NVX];
   auto load_chunk = [&](int ch) {
-    const int pix0 = ch * KP;
-    unsigned off[NVX], offy[NVY];
-#pragma unroll
-    for (int i = 0; i < NVX; ++i) {
-      const int row = xrow0 + i * XRS;
-      const int m = pix0 + row;
-      const int b = xb[i], oy = xoy[i], ox = xox[i];
-      {
-        int nx = ox + p.step_col;
-        const int w = nx >= p.Wc ? 1 : 0;
-        nx -= w ? p.Wc : 0;
-        int ny = oy + p.step_row + w;
-        const int h = ny >= p.Hc ? 1 : 0;
-        ny -= h ? p.Hc : 0;
-        xox[i] = nx; xoy[i] = ny; xb[i] = b + p.step_img + h;
-      }
-      const int iy = CLS ? oy + kh : oy * p.stride - p.pad + kh;
-      const int ix = CLS ? ox + kw : ox * p.stride - p.pad + kw;
-      const bool inb = CLS ? ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws)
-                           : ((unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv);
-      const bool ok = xvalid_c && row < KP && m < p.Mi && inb;
+    const bool rowok = lrow < p.Mi - ch * KP;  // the last chunk may be partial
+    const int b = xb, oy = xoy, ox = xox;
+    {
+      int nx = ox + p.step_col;
+      const int w = nx >= p.Wc ? 1 : 0;
+      nx -= w ? p.Wc : 0;
+      int ny = oy + p.step_row + w;
+      const int h = ny >= p.Hc ? 1 : 0;
+      ny -= h ? p.Hc : 0;
+      xox = nx; xoy = ny;
+      if (!lin) xb = b + p.step_img + h;
+    }
+    unsigned ox_off, oy_off;
+    if (lin) {
+      const bool inb = (unsigned)(oy + dkh) < (unsigned)Hs && (unsigned)(ox + dkw) < (unsigned)Ws;
+      ox_off = (rowok && inb) ? xoff : BUF_OOB;
+      xoff += xstep;
+    } else {
+      const int iy = oy * p.stride + dkh, ix = ox * p.stride + dkw;
+      const bool inb = (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
       const int pix = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
-      off[i] = ok ? (unsigned)(pix * Cs + xcl) * (unsigned)sizeof(T) : BUF_OOB;
-      if constexpr (CLS) {  // dY row of the same pixel (BMW == BNW: identical loader roles)
-        const bool oky = yvalid_c && row < KP && m < p.Mi;
-        const int my = (b * p.Ho + 2 * oy + cpy) * p.Wo + 2 * ox + cpx;
-        offy[i] = oky ? (unsigned)(my * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB;
-      }
+      ox_off = (rowok && inb) ? (unsigned)(pix * Cs + xcl) * (unsigned)sizeof(T) : BUF_OOB;
     }
-    if constexpr (!CLS) {
+    if constexpr (CLS) oy_off = rowok ? yoff - __umul24((unsigned)ox, yox2) : BUF_OOB;
+    else oy_off = rowok ? yoff : BUF_OOB;
+    yoff += ystep;
 #pragma unroll
-      for (int i = 0; i < NVY; ++i) {
-        const int row = yrow0 + i * YRS;
-        const int m = pix0 + row;
-        const bool ok = yvalid_c && row < KP && m < p.M;
-        offy[i] = ok ? (unsigned)(m * p.Cout + yco) * (unsigned)sizeof(T) : BUF_OOB;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NVY; ++i) ry[i] = buf_load16(rdy, offy[i]);
+    for (int j = 0; j < NVY; ++j) ry[j] = buf_load16s(rdy, ycol[j] ? oy_off : BUF_OOB, j * VSTEP);
     if (from0) {
 #pragma unroll
-      for (int i = 0; i < NVX; ++i) rx[i] = buf_load16(rx0, off[i]);
+      for (int j = 0; j < NVX; ++j) rx[j] = buf_load16s(rx0, xcol[j] ? ox_off : BUF_OOB, j * VSTEP);
     } else {
 #pragma unroll
-      for (int i = 0; i < NVX; ++i) rx[i] = buf_load16(rx1, off[i]);
+      for (int j = 0; j < NVX; ++j) rx[j] = buf_load16s(rx1, xcol[j] ? ox_off : BUF_OOB, j * VSTEP);
     }
   };
 
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
     unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
     // staging: this thread's VE channels of one pixel -> 8 bytes per plane (fp32) / 16 bytes (bf16)
     constexpr int VPS = 32 / VE;  // 16-byte global vectors per 32-channel subtile
-    const int ywoff = (ycv / VPS) * X3_SUB + (ycv % VPS) * (VE * 2), xwoff = (xcv / VPS) * X3_SUB + (xcv % VPS) * (VE * 2);
+    auto woff = [&](int cv) { return (cv / VPS) * X3_SUB + (cv % VPS) * (VE * 2); };
     // fragment gather: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies row q, channels 4p..
     const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
     const int rd_lane = ((grp >> 1) * 8 + q) * 64 + ((grp & 1) * 16 + 4 * pq) * 2;  // + s*16*64 + h*4*64
@@ -257,9 +261,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
 #pragma unroll
       for (int i = 0; i < NVY; ++i) {
-        const int row = yrow0 + i * YRS;
-        if (row < KP) {
-          unsigned char* d = lb + row * 64 + ywoff;
+        if (lcol + i * TPR < VY) {
+          unsigned char* d = lb + lrow * 64 + woff(lcol + i * TPR);
           if constexpr (sizeof(T) == 4) {
             uint2 h, m, l;
             wg_split3x4(ry[i], h, m, l);
@@ -273,9 +276,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
       }
 #pragma unroll
       for (int i = 0; i < NVX; ++i) {
-        const int row = xrow0 + i * XRS;
-        if (row < KP) {
-          unsigned char* d = lb + X3_OP + row * 64 + xwoff;
+        if (lcol + i * TPR < VX) {
+          unsigned char* d = lb + X3_OP + lrow * 64 + woff(lcol + i * TPR);
           if constexpr (sizeof(T) == 4) {
             uint2 h, m, l;
             wg_split3x4(rx[i], h, m, l);
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   for (int ch = chunk_begin; ch < chunk_end; ++ch) {
   #pragma unroll
       for (int i = 0; i < NVY; ++i)
-        if (yrow0 + i * YRS < KP) lds_store_as_f32<T>(&Ys[(yrow0 + i * YRS) * LY + ycv * VE], ry[i]);
+        if (lcol + i * TPR < VY) lds_store_as_f32<T>(&Ys[lrow * LY + (lcol + i * TPR) * VE], ry[i]);
   #pragma unroll
       for (int i = 0; i < NVX; ++i)
-        if (xrow0 + i * XRS < KP) lds_store_as_f32<T>(&Xs[(xrow0 + i * XRS) * LX + xcv * VE], rx[i]);
+        if (lcol + i * TPR < VX) lds_store_as_f32<T>(&Xs[lrow * LX + (lcol + i * TPR) * VE], rx[i]);
       __syncthreads();
       if (ch + 1 < chunk_end) load_chunk(ch + 1);
   #pragma unroll

@@ -913,8 +913,9 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   // gradients), d (data gradients), b (BatchNorm backward kernels) -- what each class costs on the critical path
   static const char* abl = getenv("D3F_ABLATE_BACKWARD");
   const bool skip_w = abl && strchr(abl, 'w'), skip_d = abl && strchr(abl, 'd'), skip_b = abl && strchr(abl, 'b');
+  const bool skip_r = abl && strchr(abl, 'r');  // r: the slab reduces of the weight gradients (gradients stay unwritten)
 #else
-  constexpr bool skip_w = false, skip_d = false, skip_b = false;
+  constexpr bool skip_w = false, skip_d = false, skip_b = false, skip_r = false;
 #endif
   if (!serial)
     if (int rc = ensure_streams()) return rc;
@@ -973,8 +974,9 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;  // two-source layers are never grouped
       g.partial = wpart;
       if (int rc = wgrad_launch_group(g, gp, cdtype, ws_stream)) return rc;
-      if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
-        return rc;
+      if (!skip_r)
+        if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
+          return rc;
     }
     pending.clear();
     return 0;
