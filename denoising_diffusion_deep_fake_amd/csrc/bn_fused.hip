@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     const T* __restrict__ y, const T* __restrict__ res, const T* __restrict__ yr,
     const float* __restrict__ scale_r, const float* __restrict__ shift_r, int relu, T* __restrict__ out,
     long rows, long rows_per_block) {
+  chain_priority();
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[2][BNF_SC];
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     const T* __restrict__ a, const T* __restrict__ y, T* __restrict__ dy, T* __restrict__ dres,
     int dres_acc, long rows, long rows_per_block, const float* __restrict__ mask_scale,
     const float* __restrict__ mask_shift) {
+  chain_priority();
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[3][BNF_SC];

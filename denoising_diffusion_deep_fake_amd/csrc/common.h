@@ -71,6 +71,21 @@ __device__ __forceinline__ uint4 buf_load16s(__amdgpu_buffer_rsrc_t r, unsigned 
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Wave priority of the kernels on the training step's DEPENDENT chain (forward / data-gradient convolutions, BatchNorm,
+// pooling): the weight-gradient kernels of the second stream run at the default priority 0 on the same SIMDs, and the
+// issue arbiter otherwise serves whichever wave issues matrix instructions more densely -- a faster weight-gradient
+// kernel then SLOWED the data gradients it runs next to by as much as it gained (r03: 3.40 -> 3.75 ms per step), and
+// the chain's 5 us BatchNorm kernels ran 3x longer than alone.  Stream priorities only order the dispatch of workgroups;
+// this orders the issue of instructions.  -DD3F_CHAIN_PRIO=0 builds the A/B variant.
+#ifndef D3F_CHAIN_PRIO
+#define D3F_CHAIN_PRIO 3
+#endif
+__device__ __forceinline__ void chain_priority() {
+#if D3F_CHAIN_PRIO > 0
+  __builtin_amdgcn_s_setprio(D3F_CHAIN_PRIO);
+#endif
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;    // elements per 16-byte vector
@@ -243,6 +258,22 @@ int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Co
                              int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
                              hipStream_t stream);
 
+// Deferred slab reduces: jobs collected while a gradient bucket's weight-gradient kernels are launched, run as ONE
+// kernel at the end of the bucket (every layer then owns its slab region instead of sharing one scratch).
+constexpr int WG_BATCH = 20;
+struct WgradReduceJob {
+  const float* partial;
+  float* dw;
+  int splits, CoutP, Cin, CinReal, taps, CB, nsg, VB, CinTot, c_off, fold, Cout, cz, block0, lds;
+};
+struct WgradReduceBatch {
+  WgradReduceJob job[WG_BATCH];
+  int n = 0, blocks = 0, lds = 0;
+};
+int wgrad_reduce_batch_add(WgradReduceBatch& tb, const float* partial, int splits, int CoutP, int Cout, int Cin,
+                           int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw);
+int wgrad_reduce_batch_launch(const WgradReduceBatch& tb, hipStream_t stream);
+
 // The weight gradient of one convolution as 1 or 2 passes (launch + slab reduce each): a decoder layer behind an
 // up-sampling runs WG_CLASS + WG_SKIP when the tap-parallel kernel takes it, everything else WG_WHOLE.
 struct WgradLayer {
@@ -254,5 +285,9 @@ int wgrad_layer_plan(WgradLayer& L, const WgradParams& base, int dtype);
 size_t wgrad_layer_partial_floats(const WgradLayer& L);  // slab scratch: the passes are stream-ordered, so the max
 int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                        float* dw, int CoutReal, int CinReal, int dtype, hipStream_t stream);
+size_t wgrad_layer_partial_floats_all(const WgradLayer& L);  // slab scratch when every pass keeps its slabs (deferred)
+int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
+                                float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
+                                hipStream_t stream);
 
 }  // namespace d3f

@@ -231,6 +231,7 @@ __device__ __forceinline__ long par_out_row(const ConvParams& p, int py, int px,
 // multiply-adds per output instead of 9*(C0 + C1).
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, int FAST, bool X3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  chain_priority();
   constexpr int VE = Elem<T>::VE, BKE = Elem<T>::BKE;
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / MT, FN = TN / MT;
   constexpr int NVA = BM * 8 / 256;
@@ -1285,6 +1286,7 @@ constexpr int SK_MAX = 8;    // upper bound of splitk (plan)
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+  chain_priority();
   __shared__ float red[256 * 4 * 2];
   const int VC = p.Cout / 4;   // 16-byte vectors per row; 256 % VC == 0 (plan)
   const int RP = 256 / VC;     // rows per pass

@@ -37,6 +37,7 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
 
 template <int CIN, int BN>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
+  chain_priority();
   static_assert(CIN == 16 && BN == 16, "one configuration so far");
   constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
   constexpr int CS = CIN + 4;        // dwords per staged pixel
@@ -300,6 +301,7 @@ bool conv_stem_applies(const ConvParams& p, int dtype) {
 }
 
 __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
+  chain_priority();
   constexpr int PH = ST_PH, PW = ST_PW, BN = ST_BN;
   constexpr int PR = 2 * PH + 5, PC = 2 * PW + 5;  // 21 x 69 input pixels
   constexpr int NE = (PC + 1) / 2;                 // even columns come first in a staged row

@@ -387,14 +387,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
 // sum over the four output-parity classes (py, px) of folded tap ((py*2 + px)*2 + a(py, kh))*2 + a(px, kw),
 // a(0, k) = k > 0, a(1, k) = k > 1 -- added in class order, a fixed tree.
 template <bool FOLD>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int CoutP,
-                                                           int Cin, int CinReal, int taps, int CB, int nsg, int VB,
-                                                           const WgradDst dst, int CinTot, int c_off) {
-  extern __shared__ __attribute__((aligned(16))) float row[];  // [nsg][taps][CB + 1]
-  const int co = blockIdx.x, member = blockIdx.y, c0 = blockIdx.z * CB;
+__device__ __forceinline__ void wgrad_reduce_body(float* row, const float* __restrict__ partial, int splits, int CoutP,
+                                                  int Cin, int CinReal, int taps, int CB, int nsg, int VB,
+                                                  float* __restrict__ dw, int CinTot, int c_off, int co, int c0) {
   const int rowlen = taps * Cin;
   const long n = (long)CoutP * rowlen;
-  const float* __restrict__ src = partial + (long)member * splits * n + (long)co * rowlen + c0;
+  const float* __restrict__ src = partial + (long)co * rowlen + c0;
   const int LR = CB + 1, plane = taps * LR, nvec = taps * CB / 4;
   const int sg = threadIdx.x / VB, vb = threadIdx.x - sg * VB;
   if (sg < nsg) {
@@ -430,7 +428,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   const int creal = min(CB, CinReal - c0);  // <= 0 for a chunk of padding channels only
   if constexpr (FOLD) {
-    float* __restrict__ out = dst.dw[member] + ((long)co * CinTot + c_off + c0) * 9;
+    float* __restrict__ out = dw + ((long)co * CinTot + c_off + c0) * 9;
     for (int o = threadIdx.x; o < creal * 9; o += 256) {
       const int ci = o / 9, t9 = o - ci * 9, kh = t9 / 3, kw = t9 - kh * 3;
       float s = 0.f;
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       out[o] = s;
     }
   } else {
-    float* __restrict__ out = dst.dw[member] + ((long)co * CinTot + c_off + c0) * taps;
+    float* __restrict__ out = dw + ((long)co * CinTot + c_off + c0) * taps;
     for (int o = threadIdx.x; o < creal * taps; o += 256) {
       const int ci = o / taps, tap = o - ci * taps;
       float s = row[tap * LR + ci];
@@ -454,6 +452,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       out[o] = s;
     }
   }
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int CoutP,
+                                                           int Cin, int CinReal, int taps, int CB, int nsg, int VB,
+                                                           const WgradDst dst, int CinTot, int c_off) {
+  extern __shared__ __attribute__((aligned(16))) float row[];  // [nsg][taps][CB + 1]
+  const int member = blockIdx.y;
+  wgrad_reduce_body<FOLD>(row, partial + (long)member * splits * CoutP * taps * Cin, splits, CoutP, Cin, CinReal, taps, CB,
+                          nsg, VB, dst.dw[member], CinTot, c_off, blockIdx.x, blockIdx.z * CB);
+}
+
+// Several layers' slab reduces as ONE launch (every layer keeps its own slabs until the end of its gradient bucket):
+// 47 launches of 5-30 us per step, each a short HBM-bound burst in the middle of the weight-gradient stream, become one
+// launch per bucket.  A workgroup finds its job in the table by its block index; the summation order inside a job is
+// the single-layer kernel's (bitwise the same gradients).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatch tb) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  int j = 0;
+#pragma unroll 1
+  for (int i = 1; i < tb.n; ++i) j = ((int)blockIdx.x >= tb.job[i].block0) ? i : j;
+  const WgradReduceJob& q = tb.job[j];
+  const int local = (int)blockIdx.x - q.block0;
+  const int co = local % q.Cout, cz = local / q.Cout;
+  if (q.fold)
+    wgrad_reduce_body<true>(row, q.partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, q.dw, q.CinTot,
+                            q.c_off, co, cz * q.CB);
+  else
+    wgrad_reduce_body<false>(row, q.partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, q.dw, q.CinTot,
+                             q.c_off, co, cz * q.CB);
 }
 
 struct WTile {
@@ -629,15 +657,15 @@ int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, i
   return wgrad_reduce_launch_part(partial, splits, CoutP, Cout, Cin, CinReal, CinReal, 0, KH, KW, 0, dst, stream);
 }
 
-int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
-                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
-                             hipStream_t stream) {
-  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG && Cin % 4 == 0 && CinRealPart <= Cin && Cout <= CoutP &&
-                c_off + CinRealPart <= CinRealTotal && (!fold || (KH == 3 && KW == 3)),
+// work split of one reduce: channel chunks (cz of CB channels), slab groups (nsg) and vector columns (VB) per workgroup
+static int wgrad_reduce_job(WgradReduceJob& q, const float* partial, int splits, int CoutP, int Cout, int Cin,
+                            int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw, int members) {
+  D3F_CHECK(Cin % 4 == 0 && CinRealPart <= Cin && Cout <= CoutP && c_off + CinRealPart <= CinRealTotal &&
+                (!fold || (KH == 3 && KW == 3)),
             "wgrad reduce: arguments");
   const int taps = fold ? 16 : KH * KW;
   int cz = 1;  // channel chunks: enough workgroups to fill the chip, chunks of at least 16 channels (64-byte segments)
-  while ((long)Cout * dst.n * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
+  while ((long)Cout * members * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
   const int CB = Cin / cz, nvec = taps * CB / 4;
   int nsg = nvec >= 256 ? 1 : 256 / nvec;  // slab groups: fill the 256 threads, every group gets >= 2 slabs
   if (nsg > 8) nsg = 8;
@@ -645,13 +673,48 @@ int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Co
   const int VB = nsg == 1 ? 256 : (nvec < 256 / nsg ? nvec : 256 / nsg);
   const size_t lds = (size_t)nsg * taps * (CB + 1) * sizeof(float);
   D3F_CHECK(lds <= 64 * 1024, "wgrad reduce: a %d-tap x %d-channel filter chunk exceeds the LDS tile", taps, CB);
-  const dim3 grid((unsigned)Cout, (unsigned)dst.n, (unsigned)cz);
+  q.partial = partial; q.dw = dw;
+  q.splits = splits; q.CoutP = CoutP; q.Cin = Cin; q.CinReal = CinRealPart; q.taps = taps; q.CB = CB; q.nsg = nsg;
+  q.VB = VB; q.CinTot = CinRealTotal; q.c_off = c_off; q.fold = fold ? 1 : 0; q.Cout = Cout; q.cz = cz; q.block0 = 0;
+  q.lds = (int)lds;
+  return 0;
+}
+
+int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
+                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
+                             hipStream_t stream) {
+  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG, "wgrad reduce: %d group members", dst.n);
+  WgradReduceJob q;
+  if (int rc = wgrad_reduce_job(q, partial, splits, CoutP, Cout, Cin, CinRealPart, CinRealTotal, c_off, KH, KW, fold,
+                                dst.dw[0], dst.n))
+    return rc;
+  const dim3 grid((unsigned)Cout, (unsigned)dst.n, (unsigned)q.cz);
   if (fold)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, grid, dim3(256), lds, stream, partial, splits, CoutP, Cin, CinRealPart,
-                       taps, CB, nsg, VB, dst, CinRealTotal, c_off);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, grid, dim3(256), (size_t)q.lds, stream, partial, splits, CoutP, Cin,
+                       CinRealPart, q.taps, q.CB, q.nsg, q.VB, dst, CinRealTotal, c_off);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, grid, dim3(256), lds, stream, partial, splits, CoutP, Cin, CinRealPart,
-                       taps, CB, nsg, VB, dst, CinRealTotal, c_off);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, grid, dim3(256), (size_t)q.lds, stream, partial, splits, CoutP, Cin,
+                       CinRealPart, q.taps, q.CB, q.nsg, q.VB, dst, CinRealTotal, c_off);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int wgrad_reduce_batch_add(WgradReduceBatch& tb, const float* partial, int splits, int CoutP, int Cout, int Cin,
+                           int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw) {
+  D3F_CHECK(tb.n < WG_BATCH, "wgrad reduce batch: table full");
+  WgradReduceJob& q = tb.job[tb.n];
+  if (int rc = wgrad_reduce_job(q, partial, splits, CoutP, Cout, Cin, CinRealPart, CinRealTotal, c_off, KH, KW, fold, dw, 1))
+    return rc;
+  q.block0 = tb.blocks;
+  tb.blocks += q.Cout * q.cz;
+  tb.lds = std::max(tb.lds, q.lds);
+  ++tb.n;
+  return 0;
+}
+
+int wgrad_reduce_batch_launch(const WgradReduceBatch& tb, hipStream_t stream) {
+  if (tb.n == 0) return 0;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)tb.blocks), dim3(256), (size_t)tb.lds, stream, tb);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -680,6 +743,31 @@ size_t wgrad_layer_partial_floats(const WgradLayer& L) {
   size_t n = 0;
   for (int i = 0; i < L.nparts; ++i) n = std::max(n, wgrad_partial_floats(L.part[i]));
   return n;
+}
+
+size_t wgrad_layer_partial_floats_all(const WgradLayer& L) {
+  size_t n = 0;
+  for (int i = 0; i < L.nparts; ++i) n += (wgrad_partial_floats(L.part[i]) + 63) / 64 * 64;
+  return n;
+}
+
+// the passes' launches only: every pass writes its own slab region of `partial` (wgrad_layer_partial_floats_all floats),
+// and its reduce is appended to `tb` for a later wgrad_reduce_batch_launch on the same stream
+int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
+                                float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
+                                hipStream_t stream) {
+  for (int i = 0; i < L.nparts; ++i) {
+    WgradParams w = L.part[i];
+    w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = partial;
+    if (int rc = wgrad_launch(w, dtype, stream)) return rc;
+    const int c_off = w.ci_base;
+    const int creal = std::max(0, std::min(w.patch ? w.C0 + w.C1 : w.slab_cin, CinReal - c_off));
+    if (int rc = wgrad_reduce_batch_add(tb, partial, w.splits, w.Cout, CoutReal, w.patch ? w.C0 + w.C1 : w.slab_cin, creal,
+                                        CinReal, c_off, w.KH, w.KW, w.cls, dw))
+      return rc;
+    partial += (wgrad_partial_floats(w) + 63) / 64 * 64;
+  }
+  return 0;
 }
 
 int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,

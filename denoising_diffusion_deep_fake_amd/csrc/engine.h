@@ -59,6 +59,7 @@ struct Unit {
   // gradient runs on the tap-parallel kernel -- 4/9 of the MACs on the up-sampled channels
   bool wclass = false;
   WgradLayer wl{};
+  size_t wslab_off = 0;  // this unit's own slab region (its reduce is deferred to the end of the gradient bucket)
   int Cin() const { return C0 + C1; }
 };
 

@@ -205,6 +205,7 @@ int UnetEngine::plan_unit(Unit& u) {
       const size_t wb = wgrad_layer_partial_floats(u.wl) * sizeof(float);
       if (wb > wpart_bytes) wpart_bytes = wb;
     }
+    u.wslab_off = alloc(wgrad_layer_partial_floats_all(u.wl) * sizeof(float));
   }
   if (int rc = wgrad_plan(g, dtype)) return rc;  // single-layer plan; identical layers are re-planned as a group in build()
   {
@@ -937,6 +938,16 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   static const int defer = getenv("D3F_WGRAD_DEFER") ? std::max(1, atoi(getenv("D3F_WGRAD_DEFER"))) : 3;
   std::vector<int> pending;
   int pending_segment = -1;
+  // slab reduces of the bucket's layers, deferred into one launch per bucket (every unit owns its slabs);
+  // D3F_NO_WGRAD_BATCH (debugging knob): one launch right behind every layer
+  static const bool no_batch = getenv("D3F_NO_WGRAD_BATCH") != nullptr;
+  WgradReduceBatch red;
+  auto flush_reduces = [&]() -> int {
+    if (red.n == 0) return 0;
+    const int rc = skip_r ? 0 : wgrad_reduce_batch_launch(red, ws_stream);
+    red = WgradReduceBatch();
+    return rc;
+  };
   auto flush_pending = [&]() -> int {
     if (pending.empty()) return 0;
     if (!serial) {
@@ -952,13 +963,18 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
     for (int ui : pending) {
       const Unit& u = units[ui];
-      if (u.wclass) {  // class-form passes of a layer behind an up-sampling (never grouped)
-        if (int rc = wgrad_layer_launch(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr, wpart,
-                                        grads + u.w_off, u.Cout, u.CinReal, cdtype, ws_stream))
+      const WGroup& grp = wgroups[u.wgroup];
+      if (grp.units.size() == 1) {  // (grouped launches -- a tuning knob -- keep the shared scratch and their own reduce)
+        if (red.n + u.wl.nparts > WG_BATCH)
+          if (int rc = flush_reduces()) return rc;
+        if (int rc = wgrad_layer_launch_deferred(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr,
+                                                 reinterpret_cast<float*>(ws + u.wslab_off), grads + u.w_off, u.Cout,
+                                                 u.CinReal, cdtype, red, ws_stream))
           return rc;
+        if (no_batch)
+          if (int rc = flush_reduces()) return rc;
         continue;
       }
-      const WGroup& grp = wgroups[u.wgroup];
       WgradParams g = grp.wg;
       WgradGroup gp;
       WgradDst gd;
@@ -985,6 +1001,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
     if (op.segment != pending_segment) {
       if (int rc = flush_pending()) return rc;
+      if (int rc = flush_reduces()) return rc;  // the bucket's gradients are final behind this launch
       pending_segment = op.segment;
     }
     if (aux_used && !aux_joined && op.segment != 0) {
@@ -1128,6 +1145,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
   }
   if (int rc = flush_pending()) return rc;
+  if (int rc = flush_reduces()) return rc;
   if (!serial && side_used) side_dirty_ = true;
   if (!serial && !join) {
     // data-parallel caller: the caller's stream (the critical path) is NOT held back.  The side stream waits for the

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ dA, float* __restrict__ dB,
                                                        float* __restrict__ dC,
                                                        float* __restrict__ partial) {
+  chain_priority();
   __shared__ float tx[SS_IN * SS_LD], ty[SS_IN * SS_LD];
   __shared__ float vv[5][SS_T * SS_LD];
   __shared__ float wsum[4];
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void ssim_mse_bwd_kernel(
     int H, int W, const float* __restrict__ dA, const float* __restrict__ dB,
     const float* __restrict__ dC, float ssim_coef, float mse_coef, float* __restrict__ grad,
     float* __restrict__ partial_mse) {
+  chain_priority();
   __shared__ float t3[3][SS_IN * SS_LD];
   __shared__ float vv[3][SS_T * SS_LD];
   __shared__ float wsum[4];
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             const float* __restrict__ part_mse,
                                                             int n_mse, double n_ssim_elems,
                                                             double n_elems, float* __restrict__ out) {
+  chain_priority();
   __shared__ double red[2][256];
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < n_ss; i += 256) a += (double)part_ss[i];

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
     float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  chain_priority();
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < tiles; t += 256) {
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const T* __restrict__ res, const T* __restrict__ yr, const float* __restrict__ scale_r,
     const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int c0 = (int)((i * N) % C);
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
     long rows, int C, const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   __shared__ float red[256 * N * 2];
   const int VC = C / N;        // vectors per row (power of two, <= 256)
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  chain_priority();
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < nblocks; t += 256) {
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
     T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C,
     const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int c0 = (int)((i * N) % C);
@@ -431,6 +436,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                           uint8_t* __restrict__ idx, int B, int H,
                                                           int W, int C) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   const int Ho = H / 2, Wo = W / 2, VC = C / N;
   const long total = (long)B * Ho * Wo * VC;
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                                                           const uint8_t* __restrict__ idx,
                                                           T* __restrict__ din, int accumulate, int B,
                                                           int H, int W, int C) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   const int Ho = H / 2, Wo = W / 2, VC = C / N;
   const long total = (long)B * H * W * VC;
@@ -561,6 +568,7 @@ int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, voi
 template <typename T>
 __global__ __launch_bounds__(256) void sum2x2_kernel(const T* __restrict__ dfull, T* __restrict__ dlow,
                                                      int B, int Hl, int Wl, int C) {
+  chain_priority();
   constexpr int N = V16<T>::N;
   const int VC = C / N;
   const long total = (long)B * Hl * Wl * VC;
