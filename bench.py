@@ -43,6 +43,11 @@ def parse():
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
+    ap.add_argument("--graph-step", default="auto", choices=["auto", "on", "off"],
+                    help="whole optimiser step replayed from one captured hipGraph (graph_step.py; single GPU).  auto: on "
+                         "where the host's launch loop is within ~20 %% of the GPU time -- bf16 / f32x3, images below "
+                         "256x256, batches below 16 -- and off for the fp32 256x256 headline (GPU-bound; the same eager "
+                         "path the N > 1 runs take)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N=1: price the data-parallel machinery on ONE GPU -- the same step plain and with the 4 gradient "
                          "buckets all-reduced over a single-rank RCCL group (BucketAllReducer(force=True)); one JSON line")
@@ -105,6 +110,14 @@ ALT_NOTES = {
 }
 
 
+def wants_graph_step(args, dtype, world):
+    if world > 1 or args.graph_step == "off":
+        return False
+    if args.graph_step == "on":
+        return True
+    return dtype != "f32" or args.size < 256 or args.batch < 16
+
+
 def alt_dtype(args, dev, dtype):
     """Secondary figures of the default N=1 run, NOT the headline: the same training step with
     compute_dtype="f32x3" (fp32 tensors and fp32 accumulation, every conv product formed from six bf16 MFMAs over an
@@ -115,12 +128,15 @@ def alt_dtype(args, dev, dtype):
     lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
                     num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
                     mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
-                    augment=False, precision=dtype).to(dev).train()
+                    augment=False, precision=dtype, graph_step=wants_graph_step(args, dtype, 1)).to(dev).train()
     (opt,), _ = lit.configure_optimizers()
+    lit.attach_optimizers([opt])
     nb = 4
     data = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
 
     def step(i):
+        if not lit.automatic_optimization:  # the whole step is one captured graph (manual optimisation)
+            return lit.training_step({"image": data[i % nb], "index": None}, i)
         opt.zero_grad(set_to_none=True)
         loss = lit.training_step({"image": data[i % nb], "index": None}, i)
         loss.backward()
@@ -136,7 +152,7 @@ def alt_dtype(args, dev, dtype):
     dt = time.perf_counter() - t0
     return {"value": round(args.batch * args.steps / dt, 2), "unit": "images/sec",
             "ms_per_step": round(1e3 * dt / args.steps, 3), "final_loss": round(float(loss.item()), 5),
-            "note": ALT_NOTES[dtype]}
+            "graph_step": not lit.automatic_optimization, "note": ALT_NOTES[dtype]}
 
 
 def extra_workload(args):
@@ -418,14 +434,18 @@ def main():
     lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
                     num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
                     mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
-                    augment=False, precision=args.dtype).to(dev).train()
+                    augment=False, precision=args.dtype,
+                    graph_step=wants_graph_step(args, args.dtype, world)).to(dev).train()
     (opt,), _ = lit.configure_optimizers()
+    lit.attach_optimizers([opt])
     DataParallel(lit.model, opt)
     torch.manual_seed(1000 + rank)  # distinct noise stream per rank
     nb = 4  # resident synthetic batches, distinct per rank
     data = [synthetic_face_crops(args.batch, args.size, seed=1234 + 97 * rank + i, device=dev) for i in range(nb)]
 
     def step(i):
+        if not lit.automatic_optimization:  # the whole step is one captured graph (manual optimisation)
+            return lit.training_step({"image": data[i % nb], "index": None}, i)
         opt.zero_grad(set_to_none=True)
         loss = lit.training_step({"image": data[i % nb], "index": None}, i)
         loss.backward()
@@ -462,6 +482,8 @@ def main():
     diag = min(args.steps, 5)
     sampled = diag
     if use_events:
+        if lit._graph_step is not None:
+            lit._graph_step.use_graph = False  # per-launch events need the launches themselves: same step, eagerly
         for classes in (3, 4):
             _lib.check(L.d3f_profile_classes(classes))
             _lib.check(L.d3f_profile_enable(diag * 128 + 64))
@@ -501,6 +523,8 @@ def main():
                                f"random-init weights, train-mode BatchNorm",
                    "image_size": args.size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "final_loss": round(lossv, 5),
+                   # True: the optimiser step is replayed from one captured hipGraph (--graph-step; never at N > 1)
+                   "graph_step": not lit.automatic_optimization,
                    # what the collective layer saw (None at N=1: no process group, no exchange step)
                    "backend": dist.get_backend() if world > 1 else None,
                    "ranks_seen": dist.get_world_size() if world > 1 else 1,

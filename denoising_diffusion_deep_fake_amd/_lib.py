@@ -59,6 +59,8 @@ PROTOTYPES = {
     "d3f_unet_backward_nojoin": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "d3f_unet_side_stream": (_i, [_p, C.POINTER(_p)]),
     "d3f_unet_backward_join": (_i, [_p, _p]),
+    "d3f_adam_coefficients": (_i, [_f, _f, _f, _f, _i, _f, C.POINTER(_f)]),
+    "d3f_unet_train_step": (_i, [_p, _p, _f, _f, _f, _p, _i, _p]),
     "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
     "d3f_unet_export_shape": (_i, [_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "d3f_conv_upsample_folded": (_i, [_i, _p]),

@@ -303,6 +303,27 @@ int d3f_unet_backward_join(d3f_unet_t h, void* stream) {
   D3F_CHECK(h, "unet_backward_join: null handle");
   return h->e.backward_join((hipStream_t)stream);
 }
+int d3f_adam_coefficients(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float coef[8]) {
+  D3F_CHECK(coef && step >= 1, "adam_coefficients: step counts from 1");
+  adam_coefficients(lr, beta1, beta2, eps, step, grad_scale, coef);
+  return 0;
+}
+int d3f_unet_train_step(d3f_unet_t h, const d3f_step_buffers* b, float lam, float input_min, float input_max,
+                        void* workspace, int use_graph, void* stream) {
+  D3F_CHECK(h && b && workspace, "unet_train_step: null argument");
+  D3F_CHECK(b->params && b->bnstats && b->grads && b->exp_avg && b->exp_avg_sq && b->image && b->noise && b->y_uniform &&
+                b->noisy && b->pred && b->grad_pred && b->loss_out && b->loss_workspace && b->adam_coef,
+            "unet_train_step: null buffer");
+  UnetEngine::StepArgs a;
+  std::memset(&a, 0, sizeof(a));  // (the struct is compared bytewise as the graph's key)
+  a.params = b->params; a.bnstats = b->bnstats; a.grads = b->grads; a.exp_avg = b->exp_avg; a.exp_avg_sq = b->exp_avg_sq;
+  a.image = b->image; a.noise = b->noise; a.y_uniform = b->y_uniform;
+  a.noisy = b->noisy; a.pred = b->pred; a.gpred = b->grad_pred; a.loss_out = b->loss_out;
+  a.loss_ws = reinterpret_cast<float*>(b->loss_workspace);
+  a.adam_coef = b->adam_coef;
+  a.lam = lam; a.lo = input_min; a.hi = input_max;
+  return h->e.train_step(a, workspace, use_graph, (hipStream_t)stream);
+}
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream) {
   D3F_CHECK(h && name && workspace && out_nchw, "unet_export: null argument");
   return h->e.export_tensor(name, workspace, out_nchw, (hipStream_t)stream);

@@ -116,6 +116,18 @@ class UnetEngine {
   // eval-mode forward (f32 NCHW in / out) replayed from a hipGraph captured once per set of pointers -- the
   // "hipGraph-captured denoise step" of BASELINE.json configs[4]; bit-identical to forward(training = 0)
   int forward_graph(const float* params, float* bnstats, const float* x, float* out, void* ws, hipStream_t s) const;
+  // One whole training step of the noisy -> clean objective (d3f/train_denoiser/lit_module.py:107-126 + Lightning's
+  // backward / optimizer step) as ONE call: pack -> noise blend -> forward -> (MSE + 1 - SSIM) / 2 -> backward -> Adam.
+  // use_graph: the ~330 launches over the engine's streams are captured once per set of pointers and replayed with one
+  // hipGraphLaunch on the caller's stream (the small configurations are bound by the host's launch loop, not the GPU).
+  struct StepArgs {
+    float* params; float* bnstats; float* grads; float* exp_avg; float* exp_avg_sq;
+    const float* image; const float* noise; const float* y_uniform;
+    float* noisy; float* pred; float* gpred; float* loss_out; float* loss_ws;
+    const float* adam_coef;  // device: adam_coefficients()
+    float lam, lo, hi;
+  };
+  int train_step(const StepArgs& a, void* ws, int use_graph, hipStream_t s) const;
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
   int export_shape(const char* name, int32_t dims[3]) const;
 
@@ -190,6 +202,10 @@ class UnetEngine {
   int wait_for_packed_weights(hipStream_t s) const;
   mutable hipStream_t gstream_ = nullptr;
   mutable GraphSlot g_predict_, g_eval_;
+  int train_step_launches(const StepArgs& a, void* ws, hipStream_t s) const;
+  mutable hipGraphExec_t g_step_ = nullptr;
+  mutable StepArgs g_step_key_{};
+  mutable const void* g_step_ws_ = nullptr;
   mutable hipEvent_t ev_gin_ = nullptr, ev_gout_ = nullptr;
   size_t head_nchw_off = 0;
   size_t ws_top = 0;

@@ -803,6 +803,57 @@ int UnetEngine::forward_graph(const float* params_, float* bnstats, const float*
   return graph_replay(g_eval_, key, cst, s, [&](hipStream_t gs) { return forward(params_, bnstats, x, out, ws_, 0, gs); });
 }
 
+int UnetEngine::train_step_launches(const StepArgs& a, void* ws_, hipStream_t s) const {
+  const long per_image = (long)in_channels * H * W;
+  if (int rc = pack_weights(a.params, ws_, s)) return rc;
+  if (int rc = noise_blend_launch(a.image, a.noise, a.y_uniform, a.lam, a.noisy, nullptr, B, per_image, s)) return rc;
+  if (int rc = forward(a.params, a.bnstats, a.noisy, a.pred, ws_, 1, s)) return rc;
+  if (int rc = mse_ssim_loss_launch(a.pred, a.image, a.lo, a.hi, a.loss_out, a.gpred, a.loss_ws, B, H, W, s)) return rc;
+  if (int rc = backward(a.params, a.gpred, a.grads, ws_, 0, num_segments, s, 1)) return rc;
+  return adam_step_dev_launch(a.params, a.grads, a.exp_avg, a.exp_avg_sq, param_floats, a.adam_coef, s);
+}
+
+int UnetEngine::train_step(const StepArgs& a, void* ws_, int use_graph, hipStream_t s) const {
+  D3F_CHECK(in_channels == 3 && classes == 3, "train_step: the (MSE + 1 - SSIM) / 2 objective is defined on 3-channel images");
+  if (!use_graph) return train_step_launches(a, ws_, s);
+  if (int rc = wait_for_packed_weights(s)) return rc;  // (a pack enqueued eagerly before this call)
+  if (int rc = ensure_streams()) return rc;
+  if (gstream_ == nullptr) {
+    D3F_HIP(hipStreamCreateWithFlags(&gstream_, hipStreamNonBlocking));
+    D3F_HIP(hipEventCreateWithFlags(&ev_gin_, hipEventDisableTiming));
+    D3F_HIP(hipEventCreateWithFlags(&ev_gout_, hipEventDisableTiming));
+  }
+  const bool same = g_step_ != nullptr && g_step_ws_ == ws_ && memcmp(&a, &g_step_key_, sizeof(StepArgs)) == 0;
+  if (!same) {
+    if (g_step_) {
+      (void)hipGraphExecDestroy(g_step_);
+      g_step_ = nullptr;
+    }
+    // The capture spans three streams: the capture stream (the dependent chain), the weight-gradient stream and the
+    // late weight packing join it through the events the eager path uses (record on a capturing stream + wait on
+    // another pulls that stream into the capture) and are joined back before the capture ends (backward joins the side
+    // stream; the pack events are waited for by the forward pass).
+    hipGraph_t graph = nullptr;
+    D3F_HIP(hipStreamBeginCapture(gstream_, hipStreamCaptureModeThreadLocal));
+    const int rc = train_step_launches(a, ws_, gstream_);
+    const hipError_t e = hipStreamEndCapture(gstream_, &graph);
+    pack_pending_ = pack_mid_pending_ = false;  // (consumed inside the capture)
+    side_dirty_ = false;
+    if (rc != 0) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    D3F_HIP(e);
+    const hipError_t ei = hipGraphInstantiate(&g_step_, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    D3F_HIP(ei);
+    g_step_key_ = a;
+    g_step_ws_ = ws_;
+  }
+  D3F_HIP(hipGraphLaunch(g_step_, s));  // stream-ordered on the caller's stream: no extra events
+  return 0;
+}
+
 // the packed weights of the later layers may still be in flight on the side stream: order `s` behind them (outside
 // any capture: the replay stream is ordered after `s`)
 int UnetEngine::wait_for_packed_weights(hipStream_t s) const {
@@ -860,6 +911,7 @@ int UnetEngine::graph_replay(GraphSlot& slot, const void* const key[5], const fl
 UnetEngine::~UnetEngine() {
   if (g_predict_.exec) (void)hipGraphExecDestroy(g_predict_.exec);
   if (g_eval_.exec) (void)hipGraphExecDestroy(g_eval_.exec);
+  if (g_step_) (void)hipGraphExecDestroy(g_step_);
   if (ev_gin_) (void)hipEventDestroy(ev_gin_);
   if (ev_gout_) (void)hipEventDestroy(ev_gout_);
   if (gstream_) (void)hipStreamDestroy(gstream_);

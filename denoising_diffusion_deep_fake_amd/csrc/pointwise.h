@@ -130,6 +130,9 @@ int mse_ssim_loss_launch(const float* pred, const float* target, float in_min, f
                          int B, int H, int W, hipStream_t stream);
 int adam_step_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, hipStream_t stream);
+void adam_coefficients(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float coef[8]);
+int adam_step_dev_launch(float* p, const float* g, float* m, float* v, long n, const float* coef_dev,
+                         hipStream_t stream);
 int ema_lerp_launch(float* ema, const float* online, long n, float weight, hipStream_t stream);
 
 }  // namespace d3f

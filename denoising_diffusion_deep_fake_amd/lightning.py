@@ -26,6 +26,19 @@ class LightningModule(nn.Module):
         self.__dict__["_hparams"] = AttributeDict()
         self.__dict__["trainer"] = None
         self.__dict__["_logged"] = {}
+        self.__dict__["_manual_optimizers"] = None
+        self.automatic_optimization = True  # False: training_step runs backward + optimiser step itself
+
+    def optimizers(self):
+        """the optimizer(s) of this module, as pytorch_lightning's `self.optimizers()` (manual optimisation)"""
+        opts = self.trainer.optimizers if self.trainer is not None else self._manual_optimizers
+        if opts is None:
+            raise RuntimeError("optimizers(): no trainer attached and attach_optimizers() was not called")
+        return opts[0] if len(opts) == 1 else list(opts)
+
+    def attach_optimizers(self, optimizers):
+        """stand-alone use (no Trainer): the optimizers `self.optimizers()` hands to a manual-optimisation step"""
+        self.__dict__["_manual_optimizers"] = list(optimizers)
 
     def save_hyperparameters(self, *args, **kwargs):
         # pytorch_lightning collects the caller's __init__ arguments; the reference's modules are all

@@ -53,6 +53,11 @@ class LitModule(LightningModule):
         self.model = self.create_model_instance()
         self.training_criterion = MseStructuralSimilarityLoss(-1.0, 1.0)
         self.shared_augmentation_sequence = self.create_shared_augmentation_sequence()
+        # graph_step: true -- the whole optimiser step as one captured hipGraph (graph_step.py).  Lightning's MANUAL
+        # optimisation contract: training_step does its own backward and optimiser step, the trainer only calls it.
+        # Single GPU only; worth it where the host's launch loop is close to the GPU time (128x128, bf16, bs 8).
+        self.automatic_optimization = not self.hparams.get("graph_step", False)
+        self.__dict__["_graph_step"] = None
 
     def create_model_instance(self):
         p = self.hparams
@@ -101,6 +106,16 @@ class LitModule(LightningModule):
         if self.hparams.get("augment", True):
             with torch.no_grad():
                 image = self.shared_augmentation_sequence(image)
+        if not self.automatic_optimization:
+            if self._graph_step is None:
+                from ..graph_step import GraphTrainStep
+                opt = self.optimizers()
+                self.__dict__["_graph_step"] = GraphTrainStep(self.model, opt, self.hparams.noise_exponential_sampling_lambda,
+                                                              self.training_criterion.input_min_value,
+                                                              self.training_criterion.input_max_value)
+            loss = self._graph_step(image)
+            self.log("loss", loss)
+            return loss
         image_noisy = self.blend_random_amount_of_noise_with_each_sample(image)
         image_prediction = self.model(image_noisy)
         loss = self.training_criterion(image_prediction, image)

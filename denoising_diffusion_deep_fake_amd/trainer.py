@@ -349,7 +349,11 @@ class Trainer:
                     self._batches_done = batch_idx + 1
                     continue
                 batch = _to_device(batch, device)
-                for oi, opt in enumerate(self.optimizers):
+                if not getattr(model, "automatic_optimization", True):
+                    # manual optimisation: the module's training_step runs backward and its optimiser step(s) itself
+                    model.training_step(batch, batch_idx)
+                    self.global_step += len(self.optimizers)
+                for oi, opt in enumerate(self.optimizers if getattr(model, "automatic_optimization", True) else []):
                     if len(self.optimizers) > 1:  # toggle_optimizer
                         for oj, ps in enumerate(opt_params):
                             for p in ps:

@@ -123,6 +123,30 @@ int d3f_unet_backward_nojoin(d3f_unet_t h, const float* params, const float* gra
                              void* workspace, int seg_begin, int seg_end, void* stream);
 int d3f_unet_side_stream(d3f_unet_t h, void** stream_out);
 int d3f_unet_backward_join(d3f_unet_t h, void* stream);
+/* One whole optimiser step of the reference's noisy -> clean objective as ONE call -- what Lightning's automatic
+ * optimisation runs around d3f/train_denoiser/lit_module.py:107-126 (and training_denoise_step_for_one_model,
+ * d3f/train_deep_fake/lit_module.py:162-181): pack weights -> blend_random_amount_of_noise_with_each_sample (the noise
+ * and the uniform draws come from the caller: RNG stays outside) -> forward -> MseStructuralSimilarityLoss -> backward ->
+ * Adam.  use_graph != 0: the ~330 kernel launches over the engine's streams are captured into a hipGraph on first use
+ * (per set of pointers) and replayed with one launch; results are bit-identical to the separate calls.  Every buffer is
+ * the caller's and must stay where it is between calls (pointers are baked into the graph); `adam_coef` is DEVICE memory
+ * holding the 8 floats d3f_adam_coefficients() computes on the host for this step (lr, betas, bias corrections), copied
+ * there stream-ordered before the call. */
+typedef struct d3f_step_buffers {
+  float* params; float* bnstats; float* grads; float* exp_avg; float* exp_avg_sq;  /* flat buffers of the network */
+  const float* image;      /* [B][3][H][W] clean batch = the loss target */
+  const float* noise;      /* randn, same shape */
+  const float* y_uniform;  /* rand(B) */
+  float* noisy;            /* scratch [B][3][H][W] */
+  float* pred;             /* network output [B][3][H][W] */
+  float* grad_pred;        /* d loss / d pred */
+  float* loss_out;         /* {loss, mse, ssim} */
+  void* loss_workspace;    /* d3f_mse_ssim_loss_workspace_bytes(B, H, W) */
+  const float* adam_coef;  /* device, 8 floats */
+} d3f_step_buffers;
+int d3f_adam_coefficients(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float coef[8]);
+int d3f_unet_train_step(d3f_unet_t h, const d3f_step_buffers* buffers, float lambda, float input_min, float input_max,
+                        void* workspace, int use_graph, void* stream);
 /* debugging / tests: copy an internal activation ("<conv name>:y" raw conv output, ":a" post
  * BN+ReLU, ":da" its gradient) to NCHW f32 */
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream);

@@ -518,3 +518,73 @@ def test_ragged_last_batch_and_mid_epoch_resume(tmp_path):
     rest = [i for b in seen for i in b]
     assert len(first) == 8 and len(rest) == 2 and sorted(first + rest) == list(range(10))
     assert tr2.lr_schedulers[0].last_epoch == 1
+
+
+@pytest.mark.parametrize("dtype,shape", [("f32", (4, 64, 64)), ("bf16", (4, 64, 64)), ("f32", (16, 128, 128))],
+                         ids=["f32_4x64", "bf16_4x64", "f32_16x128"])
+def test_graph_train_step_is_bitwise_the_eager_step(dtype, shape):
+    """GraphTrainStep (d3f_unet_train_step: pack -> blend -> forward -> loss -> backward -> Adam captured into one
+    hipGraph) against the step Lightning's automatic optimisation runs around training_step
+    (d3f/train_denoiser/lit_module.py:107-126): same seeds, five steps with a learning-rate change in between --
+    parameters, BatchNorm statistics, Adam moments and every loss value must be bit-identical, replayed (graph), eager
+    inside the one call (use_graph=False) and through the separate calls."""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    B, H, W = shape
+    hp = dict(HP_DENOISER, batch_size=B, image_size=H, precision=dtype, augment=False)
+    data = [synthetic_face_crops(B, (H, W), seed=30 + i, device="cuda") for i in range(2)]
+
+    def run(mode):
+        torch.manual_seed(5)
+        lit = LitModule(**dict(hp, graph_step=mode != "separate")).cuda().train()
+        (opt,), _ = lit.configure_optimizers()
+        lit.attach_optimizers([opt])
+        if mode != "separate":
+            from denoising_diffusion_deep_fake_amd.graph_step import GraphTrainStep
+            lit.__dict__["_graph_step"] = GraphTrainStep(lit.model, opt, hp["noise_exponential_sampling_lambda"], -1.0, 1.0,
+                                                         use_graph=mode == "graph")
+        torch.manual_seed(77)
+        losses = []
+        for i in range(5):
+            if i == 3:
+                opt.param_groups[0]["lr"] *= 0.5   # what the per-epoch cosine schedule does
+            if mode == "separate":
+                opt.zero_grad(set_to_none=True)
+                loss = lit.training_step({"image": data[i % 2], "index": None}, i)
+                loss.backward()
+                opt.step()
+            else:
+                loss = lit.training_step({"image": data[i % 2], "index": None}, i)
+            losses.append(float(loss.item()))
+        m = lit.model
+        return (losses, m.flat_params.clone(), m.flat_bn_stats.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                opt._step, m.flat_grads.clone())
+
+    ref = run("separate")
+    for mode in ("graph", "one_call_eager"):
+        got = run(mode)
+        assert got[0] == ref[0], (mode, got[0], ref[0])
+        for k in range(1, 5):
+            assert torch.equal(got[k], ref[k]), (mode, k)
+        assert got[5] == ref[5] == 5 and torch.equal(got[6], ref[6])
+    assert ref[0][-1] < ref[0][0]   # and it learns
+
+
+def test_graph_train_step_refuses_data_parallel_and_eval():
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd._lib import D3FError
+    from denoising_diffusion_deep_fake_amd.graph_step import GraphTrainStep
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    opt = FusedAdam(net.parameters(), lr=1e-3, module=net)
+    step = GraphTrainStep(net, opt, 5.0)
+    x = torch.zeros(2, 3, 32, 32, device="cuda")
+    net.set_grad_sync(lambda seg, g: None)
+    with pytest.raises(D3FError, match="single-GPU"):
+        step(x)
+    net.set_grad_sync(None)
+    net.eval()
+    with pytest.raises(D3FError, match="train mode"):
+        step(x)
+    with pytest.raises(TypeError):
+        GraphTrainStep(net, torch.optim.Adam(net.parameters()), 5.0)
