@@ -43,11 +43,11 @@ def parse():
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
-    ap.add_argument("--graph-step", default="auto", choices=["auto", "on", "off"],
-                    help="whole optimiser step replayed from one captured hipGraph (graph_step.py; single GPU).  auto: on "
-                         "where the host's launch loop is within ~20 %% of the GPU time -- bf16 / f32x3, images below "
-                         "256x256, batches below 16 -- and off for the fp32 256x256 headline (GPU-bound; the same eager "
-                         "path the N > 1 runs take)")
+    ap.add_argument("--graph-step", default="off", choices=["on", "off"],
+                    help="on: the whole optimiser step replayed from one captured hipGraph (graph_step.py; single GPU).  "
+                         "Bit-identical to the eager step, and SLOWER on this ROCm (measured r03: bf16 4.6 -> 10.9 ms, "
+                         "128x128 3.8 -> 11.5 ms per step: a replayed graph whose nodes span three captured streams costs "
+                         "~30 us per node; captured on one stream it equals the eager single-stream step) -- off by default")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N=1: price the data-parallel machinery on ONE GPU -- the same step plain and with the 4 gradient "
                          "buckets all-reduced over a single-rank RCCL group (BucketAllReducer(force=True)); one JSON line")
@@ -111,11 +111,7 @@ ALT_NOTES = {
 
 
 def wants_graph_step(args, dtype, world):
-    if world > 1 or args.graph_step == "off":
-        return False
-    if args.graph_step == "on":
-        return True
-    return dtype != "f32" or args.size < 256 or args.batch < 16
+    return world == 1 and args.graph_step == "on"
 
 
 def alt_dtype(args, dev, dtype):

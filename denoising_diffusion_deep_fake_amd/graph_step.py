@@ -3,10 +3,16 @@
 What Lightning's automatic optimisation runs around the reference's `training_step`
 (d3f/train_denoiser/lit_module.py:107-126; d3f/train_deep_fake/lit_module.py:162-181 for one net of the pair) --
 zero_grad, blend noise, U-Net forward, MseStructuralSimilarityLoss, backward, Adam step -- is ~330 kernel launches over
-three streams.  At 256x256 in fp32 the GPU needs longer for them than the host needs to launch them; at 128x128, in
-bf16, or at bs 8 the host's launch loop (~3 ms per step) is within 10-20 % of the GPU time and the chain's stream idles
-between launches.  `GraphTrainStep` hands the step to `d3f_unet_train_step`, which captures the launch sequence once
-(per set of buffers) and replays it with a single hipGraphLaunch: same kernels, same order, bit-identical parameters.
+three streams.  `GraphTrainStep` hands the step to `d3f_unet_train_step`, which captures the launch sequence once
+(per set of buffers) and replays it with a single hipGraphLaunch: same kernels, same order, bit-identical parameters
+(tests/test_gpu_training.py).
+
+MEASURED (MI355X, ROCm 7.0, round 3 -- profiles/README.md): the replay is SLOWER than the eager step -- bf16 256x256
+4.6 -> 10.9 ms, fp32 128x128 3.8 -> 11.5 ms, fp32 256x256 8.3 -> 13.7 ms per step: ~30 us per node for a graph whose
+nodes span three captured streams; captured on ONE stream (D3F_SERIAL_BACKWARD=1 D3F_NO_ASYNC_PACK=1) it merely equals
+the eager single-stream step (5.09 vs 5.11 ms), i.e. even the small configurations are bound by the GPU's own
+kernel-to-kernel dispatch latency, not by the host's launch loop (untraced host loop 3.4 ms per step,
+profiles/r03_b_hostprobe.txt).  The class therefore stays opt-in (`graph_step: true`, `bench.py --graph-step on`).
 
 Random numbers stay outside the graph (torch's generator, the reference's order: randn for the noise first, then rand
 for the blend ratios); so do Adam's per-step scalars, which travel as 8 floats in device memory.  Single GPU only: the

@@ -55,7 +55,9 @@ class LitModule(LightningModule):
         self.shared_augmentation_sequence = self.create_shared_augmentation_sequence()
         # graph_step: true -- the whole optimiser step as one captured hipGraph (graph_step.py).  Lightning's MANUAL
         # optimisation contract: training_step does its own backward and optimiser step, the trainer only calls it.
-        # Single GPU only; worth it where the host's launch loop is close to the GPU time (128x128, bf16, bs 8).
+        # Single GPU only.  Measured on ROCm 7.0 / MI355X (profiles/README.md, round 3): bit-identical and SLOWER than the
+        # eager step (the replay of a graph spanning the engine's three streams costs ~30 us per node), so it is off
+        # unless asked for.
         self.automatic_optimization = not self.hparams.get("graph_step", False)
         self.__dict__["_graph_step"] = None
 
