@@ -212,15 +212,17 @@ def extra_workload(args):
         opts, _ = lit.configure_optimizers()
         batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i, device=dev), "index": None}
                  for i, k in enumerate("ab")}
+        from denoising_diffusion_deep_fake_amd.trainer import optimizer_steps
+        opt_params = [[p for g in o.param_groups for p in g["params"]] for o in opts]
+        # the trainer's own per-batch loop; denoise mode runs the two nets' steps on two streams (D3F_SEQUENTIAL_NETS=1:
+        # the sequential loop, for the A/B)
+        streams = None if os.environ.get("D3F_SEQUENTIAL_NETS") else lit.optimizer_streams(dev)
 
         def step(i):
-            for oi, opt in enumerate(opts):
-                opt.zero_grad(set_to_none=True)
-                loss = lit.training_step(batch, i, oi)
-                loss.backward()
-                opt.step()
-            return loss
-        images_per_step, name = 2 * bs, f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain"
+            return optimizer_steps(lit, opts, opt_params, batch, i, True, streams)
+        images_per_step = 2 * bs
+        name = (f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain, the two optimizer steps "
+                f"{'overlapped on two streams' if streams else 'one after the other'}")
     else:
         # BASELINE.json configs[4]: 50 sequential eval-mode forwards of a batch of 64 at 256x256, the output fed back
         # as the next input (clamped: the "re-noise" stand-in of SURVEY.md 8d), the denoise step replayed from a

@@ -142,6 +142,18 @@ class LitModule(LightningModule):
         scheduler_b = schedulers.CosineAnnealingLR(optimizer_b, T_max=p.cosine_scheduler_max_epoch)
         return [optimizer_a, optimizer_b], [scheduler_a, scheduler_b]
 
+    def optimizer_streams(self, device):
+        """one HIP stream per optimizer when the two optimizer steps of a batch are independent of each other -- denoise
+        mode: net a learns domain a, net b learns domain b, nothing is shared (d3f/train_deep_fake/lit_module.py:142-181)
+        -- so that the trainer can overlap them (trainer.optimizer_steps).  Swap mode couples them through the EMA
+        teachers (each step updates and runs the OTHER net's teacher, :183-206): sequential, None.
+        `concurrent_optimizers: false` turns it off."""
+        if self.hparams.mode != "denoise" or not self.hparams.get("concurrent_optimizers", True):
+            return None
+        if self.__dict__.get("_opt_streams") is None:
+            self.__dict__["_opt_streams"] = [torch.cuda.Stream(device=device) for _ in range(2)]
+        return self.__dict__["_opt_streams"]
+
     def configure_callbacks(self):
         return [
             LearningRateMonitor(logging_interval="step"),

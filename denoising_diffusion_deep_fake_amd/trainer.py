@@ -16,6 +16,7 @@ distributed.DataParallel, overlapped with the backward pass; every rank iterates
 dataset (DistributedSampler, reshuffled per epoch) and draws its own noise stream (seed + rank).  `self.log` values stay on the device
 and are flushed to metrics.csv every `flush_every` steps (no per-step host sync).
 """
+import contextlib
 import inspect
 import os
 import time
@@ -175,6 +176,39 @@ def _to_device(x, device):
     return x
 
 
+def optimizer_steps(model, optimizers, opt_params, batch, batch_idx, takes_idx, streams=None):
+    """Lightning 1.x automatic optimisation for one batch: for every optimizer -- toggle (only its parameters keep
+    requires_grad), zero_grad, training_step(batch, batch_idx[, optimizer_idx]), backward, step.
+
+    streams: one HIP stream per optimizer (the module's `optimizer_streams()`), for modules whose optimizer steps are
+    INDEPENDENT of each other (train_deep_fake's denoise mode: two nets, two domains).  Each step is enqueued on its
+    own stream behind the batch's stream and the batch's stream is ordered behind all of them afterwards, so the steps
+    of one batch overlap on the GPU -- at bs 8 per net a single step leaves more than half of the chip idle -- while
+    every value stays what the sequential loop computes (the random draws keep their host order)."""
+    multi = len(optimizers) > 1
+    current = torch.cuda.current_stream() if streams else None
+    for oi, opt in enumerate(optimizers):
+        if streams:
+            streams[oi].wait_stream(current)  # the batch (and the previous batch's joins) are ready
+        with (torch.cuda.stream(streams[oi]) if streams else contextlib.nullcontext()):
+            if multi:  # toggle_optimizer
+                for oj, ps in enumerate(opt_params):
+                    for p in ps:
+                        p.requires_grad_(oj == oi)
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, batch_idx, oi) if takes_idx else model.training_step(batch, batch_idx)
+            loss.backward()
+            opt.step()
+    if streams:
+        for s in streams:
+            current.wait_stream(s)
+    if multi:
+        for ps in opt_params:
+            for p in ps:
+                p.requires_grad_(True)
+    return loss
+
+
 class Trainer:
     def __init__(self, max_epochs=1, max_steps=-1, callbacks=None, log_every_n_steps=50, gpus=None,
                  accelerator=None, devices=None, default_root_dir="lightning_logs", flush_every=100,
@@ -318,6 +352,8 @@ class Trainer:
                 dist_utils.DataParallel(mod, opt)
         takes_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
+        # independent optimizer steps on their own streams (the module decides: LitModule.optimizer_streams)
+        opt_streams = model.optimizer_streams(device) if hasattr(model, "optimizer_streams") else None
 
         loaders = model.train_dataloader()
         if self._base_seed is None:  # (a resumed run keeps the checkpoint's)
@@ -353,20 +389,9 @@ class Trainer:
                     # manual optimisation: the module's training_step runs backward and its optimiser step(s) itself
                     model.training_step(batch, batch_idx)
                     self.global_step += len(self.optimizers)
-                for oi, opt in enumerate(self.optimizers if getattr(model, "automatic_optimization", True) else []):
-                    if len(self.optimizers) > 1:  # toggle_optimizer
-                        for oj, ps in enumerate(opt_params):
-                            for p in ps:
-                                p.requires_grad_(oj == oi)
-                    opt.zero_grad(set_to_none=True)
-                    loss = model.training_step(batch, batch_idx, oi) if takes_idx else model.training_step(batch, batch_idx)
-                    loss.backward()
-                    opt.step()
-                    self.global_step += 1
-                if len(self.optimizers) > 1:
-                    for ps in opt_params:
-                        for p in ps:
-                            p.requires_grad_(True)
+                else:
+                    optimizer_steps(model, self.optimizers, opt_params, batch, batch_idx, takes_idx, opt_streams)
+                    self.global_step += len(self.optimizers)
                 self._batches_done = batch_idx + 1
                 for cb in callbacks:
                     cb.on_train_batch_end(self, model)
