@@ -214,9 +214,11 @@ def extra_workload(args):
                  for i, k in enumerate("ab")}
         from denoising_diffusion_deep_fake_amd.trainer import optimizer_steps
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in opts]
-        # the trainer's own per-batch loop; denoise mode runs the two nets' steps on two streams (D3F_SEQUENTIAL_NETS=1:
-        # the sequential loop, for the A/B)
-        streams = None if os.environ.get("D3F_SEQUENTIAL_NETS") else lit.optimizer_streams(dev)
+        # the trainer's own per-batch loop; D3F_CONCURRENT_NETS=1: the two nets' steps on two streams (opt-in: measured
+        # slower, see LitModule.optimizer_streams)
+        if os.environ.get("D3F_CONCURRENT_NETS"):
+            lit.hparams["concurrent_optimizers"] = True
+        streams = lit.optimizer_streams(dev)
 
         def step(i):
             return optimizer_steps(lit, opts, opt_params, batch, i, True, streams)

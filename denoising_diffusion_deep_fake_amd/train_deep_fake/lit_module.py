@@ -147,8 +147,11 @@ class LitModule(LightningModule):
         mode: net a learns domain a, net b learns domain b, nothing is shared (d3f/train_deep_fake/lit_module.py:142-181)
         -- so that the trainer can overlap them (trainer.optimizer_steps).  Swap mode couples them through the EMA
         teachers (each step updates and runs the OTHER net's teacher, :183-206): sequential, None.
-        `concurrent_optimizers: false` turns it off."""
-        if self.hparams.mode != "denoise" or not self.hparams.get("concurrent_optimizers", True):
+        OPT-IN (`concurrent_optimizers: true`): bit-identical to the sequential loop (tests/test_gpu_training.py) but
+        measured 50 % SLOWER on MI355X / ROCm 7.0 (10.4 -> 15.5 ms per combined batch at bs 8 x 2, 256x256: four
+        streams of MFMA-bound work -- two chains, two weight-gradient streams -- serve each other worse than two; the
+        third-stream experiments of round 2 pointed the same way, profiles/README.md)."""
+        if self.hparams.mode != "denoise" or not self.hparams.get("concurrent_optimizers", False):
             return None
         if self.__dict__.get("_opt_streams") is None:
             self.__dict__["_opt_streams"] = [torch.cuda.Stream(device=device) for _ in range(2)]
