@@ -186,9 +186,13 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
   }
 }
 
-// rows per workgroup: ~512 workgroups in all, whole passes of 32 rows
-static long rows_per_block_for(long rows, int slabs) {
-  static const long wgs = getenv("D3F_BN_FUSED_WGS") ? std::max(64, atoi(getenv("D3F_BN_FUSED_WGS"))) : 512;  // tuning knob
+// rows per workgroup, whole passes of 32 rows.  Workgroups in all: ~256 for fp32 tensors, ~512 for bf16 (r03 sweep of
+// 64 ... 1024 with the chain's kernels at wave priority 3: fp32 256x256 8.88 / 8.38 / 8.30 / 8.24 / 8.28 / 8.30 / 8.35 ms
+// per step at 64 / 128 / 192 / 256 / 320 / 512 / 768 -- every workgroup repeats the slab reduce, fewer of them repeat it
+// less; bf16 4.83 / 4.58 / 4.55 at 128 / 256 / 512: half the bytes per row, the streaming part wants the parallelism)
+static long rows_per_block_for(long rows, int slabs, int dtype) {
+  static const long knob = getenv("D3F_BN_FUSED_WGS") ? std::max(64, atoi(getenv("D3F_BN_FUSED_WGS"))) : 0;  // tuning knob
+  const long wgs = knob ? knob : (dtype == D3F_F32 ? 256 : 512);
   long rb = std::max(1L, wgs / slabs);
   long rpb = (rows + rb - 1) / rb;
   rpb = (rpb + 31) / 32 * 32;
@@ -203,7 +207,7 @@ int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C
   D3F_CHECK(bn_fused_finalize_ok(dtype, stat_rows, C), "bn_finalize_apply: C=%d, %d partial rows", C, stat_rows);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
-  const long rpb = rows_per_block_for(rows, slabs);
+  const long rpb = rows_per_block_for(rows, slabs, dtype);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
   if (dtype == D3F_F32)
     hipLaunchKernelGGL(bn_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad,
@@ -327,7 +331,7 @@ int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, i
   D3F_CHECK(bn_fused_finalize_ok(dtype, nblocks, C), "bn_bwd_finalize_apply: C=%d, %d partial rows", C, nblocks);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
-  const long rpb = rows_per_block_for(rows, slabs);
+  const long rpb = rows_per_block_for(rows, slabs, dtype);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
   if (dtype == D3F_F32)
     hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, partial, nblocks, C,
