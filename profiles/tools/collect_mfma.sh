@@ -3,7 +3,7 @@
 #   bash profiles/tools/collect_mfma.sh [TAG=r02] [git head]   (on the GPU box; prints the table, writes
 #   gpurun_out/TAG_mfma_util.json -- copy it into profiles/)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_mfma_$TAG

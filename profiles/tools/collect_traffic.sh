@@ -4,7 +4,7 @@
 #   bash profiles/tools/collect_traffic.sh [TAG=r02] [git head]   (on the GPU box; writes gpurun_out/TAG_traffic.json,
 #   gpurun_out/TAG_hbm_kernels.json -- copy them into profiles/)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
