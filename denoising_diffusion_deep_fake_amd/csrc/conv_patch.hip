@@ -29,27 +29,33 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   const bool mode_ok = p.mode == CONV_RAW_STATS || p.mode == CONV_HEAD_NCHW ||
                        (p.mode == CONV_EVAL_FUSED && p.res == nullptr) ||
                        (p.mode == CONV_DGRAD && p.out_c0 == p.Cout && (p.Cout % 4) == 0);
-  return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C0 == 16 && p.C1 == 0 &&
+  // C0 == 4: the data gradient of the segmentation head (dY has 3 channels padded to 4, 16 outputs): as an implicit
+  // GEMM it ran 110 us in the traced step for 17 MB in / 67 MB out (profiles/r03_z_step_launches.txt)
+  const bool cin_ok = p.C0 == 16 || (p.C0 == 4 && p.mode == CONV_DGRAD);
+  return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
          p.shift0 == 0 && p.zi == 0 && p.Cout <= 16 && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
-         (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * 16;
+         (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
 
 template <int CIN, int BN>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
-  static_assert(CIN == 16 && BN == 16, "one configuration so far");
+  static_assert((CIN == 16 || CIN == 4) && BN == 16, "16 channels (forward / data gradient of decoder block 4, head "
+                                                      "forward) or 4 (data gradient of the head)");
   constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
-  constexpr int CS = CIN + 4;        // dwords per staged pixel
+  // dwords per staged pixel: 16-byte aligned and such that the fragment reads spread over the banks (CIN 16: +4 pad,
+  // 16-byte reads; CIN 4: stride 12, scalar reads -- 12 * row + k covers the 32 banks over 8 consecutive rows)
+  constexpr int CS = CIN == 16 ? CIN + 4 : 12;
   constexpr int KR = 9 * CIN;        // real k extent
-  constexpr int WS = KR;             // dwords per staged weight row (no pad: 16-byte chunks XOR-swizzled by the row)
+  // dwords per staged weight row (CIN 16: no pad, 16-byte chunks XOR-swizzled by the row; CIN 4: +4 pad, no swizzle)
+  constexpr int WS = CIN == 16 ? KR : KR + 4;
   constexpr int CV = CIN / 4;        // 16-byte vectors per pixel
   constexpr int NPV = PR * PC * CV;  // patch vectors
   constexpr int NWV = BN * (KR / 4); // weight vectors
   constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
   constexpr int BM = PH * PW, LDC = BN + 4, FM = PW / 16;
-  constexpr int PATCH_DW = PR * PC * CS;
-  static_assert(BM * LDC <= PATCH_DW, "the C tile aliases the patch");
+  constexpr int PATCH_DW = PR * PC * CS > BM * LDC ? PR * PC * CS : BM * LDC;  // the C tile aliases the patch
   __shared__ __attribute__((aligned(16))) float lds[PATCH_DW + BN * WS];
   float* P = lds;
   float* Wl = lds + PATCH_DW;
@@ -90,7 +96,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
     const int row = id / (KR / 4), ch = id - row * (KR / 4);
-    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[row * WS + (ch ^ ((row >> 1) & 3)) * 4]) = wv[i];
+    const int chs = CIN == 16 ? (ch ^ ((row >> 1) & 3)) : ch;
+    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[row * WS + chs * 4]) = wv[i];
   }
   __syncthreads();
 
@@ -102,25 +109,41 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   f32x4 acc[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
-  const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // a tap's four chunks are permuted by the row
+  if constexpr (CIN == 16) {
+    const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
+    const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // a tap's four chunks are permuted by the row
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const uint4 bb = *reinterpret_cast<const uint4*>(Bbase + tap * CIN);
-    uint4 a[FM];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const uint4 bb = *reinterpret_cast<const uint4*>(Bbase + tap * CIN);
+      uint4 a[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
-      a[i] = *reinterpret_cast<const uint4*>(Abase + ((kh * PC + kw) + i * 16) * CS);
-    // element index outermost: consecutive MFMAs go to different accumulators
+      for (int i = 0; i < FM; ++i)
+        a[i] = *reinterpret_cast<const uint4*>(Abase + ((kh * PC + kw) + i * 16) * CS);
+      // element index outermost: consecutive MFMAs go to different accumulators
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].x), __uint_as_float(bb.x), acc[i], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].x), __uint_as_float(bb.x), acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].y), __uint_as_float(bb.y), acc[i], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].y), __uint_as_float(bb.y), acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].z), __uint_as_float(bb.z), acc[i], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].z), __uint_as_float(bb.z), acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].w), __uint_as_float(bb.w), acc[i], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i].w), __uint_as_float(bb.w), acc[i], 0, 0, 0);
+    }
+  } else {
+    // 4 channels: one MFMA per tap and fragment, the lane's k index IS the channel (k = 3 is the zero pad channel)
+    const float* Abase = P + (wave * PC + fr) * CS + fq;
+    const float* Bbase = Wl + fr * WS + fq;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float bb = Bbase[tap * CIN];
+      float a[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = Abase[((kh * PC + kw) + i * 16) * CS];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb, acc[i], 0, 0, 0);
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
@@ -473,9 +496,10 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK(p.patch == 1 && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) && p.C0 == 16 && p.Cout <= 16,
+  D3F_CHECK(p.patch == 1 && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) && (p.C0 == 16 || p.C0 == 4) && p.Cout <= 16,
             "conv: patch params were not planned");
-  hipLaunchKernelGGL((conv_patch_kernel<16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_patch_kernel<4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }

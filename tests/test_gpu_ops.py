@@ -100,6 +100,8 @@ CASES = [
     (1, 24, 40, 64, 64, 32, 3, 1, 1, True),      # decoder 3 conv1 with ragged patch tiles
     (2, 8, 64, 16, 0, 16, 3, 1, 1, False),       # full-resolution 16-channel layer: conv_patch_kernel (4x64 tiles)
     (1, 12, 128, 16, 0, 8, 3, 1, 1, False),      # conv_patch_kernel, two tiles per row, fewer filters than the tile
+    (2, 8, 64, 16, 0, 3, 3, 1, 1, False),        # head: data gradient through conv_patch_kernel<4, 16> (dY 3 -> 4 channels)
+    (1, 12, 128, 16, 0, 3, 3, 1, 1, False),      # ... two tiles per row
     # weight gradient in output-parity-class form (WG_CLASS + WG_SKIP passes, conv_wgrad.hip): ragged class grid
     # (3 x 6 x 10 = 180 low-resolution pixels: partial last chunk, a chunk = 3 rows + 2 columns of the grid) ...
     (3, 12, 20, 128, 64, 128, 3, 1, 1, True),
