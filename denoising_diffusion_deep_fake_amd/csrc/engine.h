@@ -177,8 +177,12 @@ class UnetEngine {
   // packed on the caller's stream, the rest on the side stream while those layers already run; the forward pass
   // waits for it in front of the first later layer
   int ensure_streams() const;
-  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr, ev_pack_mid_ = nullptr;
+  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr, ev_pack_mid_ = nullptr, ev_pack_d_ = nullptr;
   mutable bool pack_pending_ = false, pack_mid_pending_ = false;
+  // opt-in (D3F_LATE_DGRAD_PACK=1): the data-gradient layouts as a FOURTH part behind the forward layouts -- nothing
+  // reads them before the backward pass, and next to the HBM-bound first kernels of the forward pass the packing's
+  // 300 MB of traffic doubles the stem's time (158 vs 71 us); measured slower overall, see pack_weights
+  mutable bool pack_d_pending_ = false;
   // Weight packing in three parts: encoder.conv1 on the caller's stream (the forward needs it at once), layer1-2 and
   // then everything else on the side stream, each behind its own event.
   int first_mid_unit_ = -1;   // first unit (index into `units`) of the second part (encoder.layer1)

@@ -574,6 +574,7 @@ int UnetEngine::ensure_streams() const {
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_done_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_mid_, hipEventDisableTiming));
+  D3F_HIP(hipEventCreateWithFlags(&ev_pack_d_, hipEventDisableTiming));
   return 0;
 }
 
@@ -588,16 +589,23 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
   // parts: 0 = the first layers (caller's stream: encoder.conv1, or everything before layer3 without a middle part),
   // 1 = layer1-2 (side stream, own event; empty without a middle part), 2 = the rest (side stream)
   auto part_of = [&](int ui) { return ui >= first_late_unit_ ? 2 : (mid > 0 && ui >= mid) ? 1 : 0; };
-  for (int part = 0; part < 3; ++part) {
+  // part 3 (tuning knob D3F_LATE_DGRAD_PACK=1, off): every data-gradient layout in its own pass behind the forward
+  // layouts.  Measured SLOWER (r03: 8.17 -> 8.27 ms, forward conv class 2.55 -> 2.63): the stem gets its 87 us back, but
+  // the extra pass then runs next to layer1-2's MFMA-bound convolutions and costs them more
+  static const bool want_late_d = getenv("D3F_LATE_DGRAD_PACK") != nullptr;
+  const bool late_d = async && want_late_d;
+  for (int part = 0; part < 4; ++part) {
     if (part == 1 && mid <= 0) continue;
+    if (part == 3 && !late_d) continue;
     PackTable t;
     t.n = 0;
     uint32_t blocks = 0;
     for (int ui = 0; ui < (int)units.size(); ++ui) {
       const Unit& u = units[ui];
-      if (first_late_unit_ > 0 && part_of(ui) != part) continue;
-      if (first_late_unit_ <= 0 && part != 0) continue;
+      if (part < 3 && first_late_unit_ > 0 && part_of(ui) != part) continue;
+      if (part < 3 && first_late_unit_ <= 0 && part != 0) continue;
       if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
+      if (part == 3 && !u.need_dgrad) continue;
       PackEntry& e = t.e[t.n++];
       const int CoutD = (int)round_up(u.Cout, ve);
       const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
@@ -614,6 +622,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
       e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
       e.has_d = u.need_dgrad ? 1 : 0;
+      e.which = part == 3 ? 2 : (late_d ? 1 : 3);
       e.conv_stride = (u.need_dgrad && u.dgrad.par) ? 2 : 1;
       const int taps = u.KH * u.KW;
       D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
@@ -640,7 +649,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       D3F_HIP(hipEventRecord(ev_pack_mid_, side_));
       pack_mid_pending_ = true;
     }
-    if (part == 2 || first_late_unit_ <= 0) {
+    if (part == 2 || (first_late_unit_ <= 0 && part == 0)) {
       for (const Unit& u : units)  // the folded decoder layers: all late
         if (u.upfold)
           if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
@@ -651,6 +660,10 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     if (part == 2 && async) {
       D3F_HIP(hipEventRecord(ev_pack_done_, side_));
       pack_pending_ = true;
+    }
+    if (part == 3) {
+      D3F_HIP(hipEventRecord(ev_pack_d_, side_));
+      pack_d_pending_ = true;
     }
   }
   return 0;
@@ -837,7 +850,7 @@ int UnetEngine::train_step(const StepArgs& a, void* ws_, int use_graph, hipStrea
     D3F_HIP(hipStreamBeginCapture(gstream_, hipStreamCaptureModeThreadLocal));
     const int rc = train_step_launches(a, ws_, gstream_);
     const hipError_t e = hipStreamEndCapture(gstream_, &graph);
-    pack_pending_ = pack_mid_pending_ = false;  // (consumed inside the capture)
+    pack_pending_ = pack_mid_pending_ = pack_d_pending_ = false;  // (consumed inside the capture)
     side_dirty_ = false;
     if (rc != 0) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -864,6 +877,10 @@ int UnetEngine::wait_for_packed_weights(hipStream_t s) const {
   if (pack_pending_) {
     D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
     pack_pending_ = false;
+  }
+  if (pack_d_pending_) {
+    D3F_HIP(hipStreamWaitEvent(s, ev_pack_d_, 0));
+    pack_d_pending_ = false;
   }
   return 0;
 }
@@ -925,6 +942,7 @@ UnetEngine::~UnetEngine() {
   if (ev_pack_in_) (void)hipEventDestroy(ev_pack_in_);
   if (ev_pack_done_) (void)hipEventDestroy(ev_pack_done_);
   if (ev_pack_mid_) (void)hipEventDestroy(ev_pack_mid_);
+  if (ev_pack_d_) (void)hipEventDestroy(ev_pack_d_);
   if (aux_) (void)hipStreamDestroy(aux_);
   if (side_) (void)hipStreamDestroy(side_);
 }
@@ -972,6 +990,10 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
 #endif
   if (!serial)
     if (int rc = ensure_streams()) return rc;
+  if (pack_d_pending_) {  // the data-gradient layouts come from the side stream (pack_weights, part 3)
+    D3F_HIP(hipStreamWaitEvent(s, ev_pack_d_, 0));
+    pack_d_pending_ = false;
+  }
   // opt-in (D3F_AUX_STREAM=1): measured 1 % SLOWER than keeping the skip gradients on the caller's stream -- a third
   // stream of MFMA-bound work slows the dependent chain's own kernels more than the moved launches save
   static const bool want_aux = getenv("D3F_AUX_STREAM") != nullptr && atoi(getenv("D3F_AUX_STREAM")) != 0;

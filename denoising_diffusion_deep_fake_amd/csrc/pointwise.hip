@@ -978,13 +978,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   __syncthreads();
   // ---- forward layout wf[n][tap*Cin + c] ----
+  if (e.which & 1)
   for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
     const int cl = i % CT, tap = (i / CT) % taps, nl = i / run;
     const int n = n0 + nl, c = c0 + cl;
     if (n < CoutPad && c < Cin)
       pack_store<T, X3>(wf, (long)n * Kpad + tap * Cin + c, (long)CoutPad * Kpad, tile[nl * stride + cl * taps + tap]);
   }
-  if (ct == 0) {  // zero tail of each row: k in [taps*Cin, Kpad)
+  if (ct == 0 && (e.which & 1)) {  // zero tail of each row: k in [taps*Cin, Kpad)
     const int k0 = taps * Cin, tail = Kpad - k0;
     for (int i = threadIdx.x; i < PACK_NT * tail; i += 256) {
       const int n = n0 + i / tail;
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
   }
   // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
-  if (e.has_d) {
+  if (e.has_d && (e.which & 2)) {
     for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
       const int nl = i % PACK_NT, slot = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
       const int n = n0 + nl, c = c0 + cl;
