@@ -61,6 +61,7 @@ PROTOTYPES = {
     "d3f_unet_backward_join": (_i, [_p, _p]),
     "d3f_adam_coefficients": (_i, [_f, _f, _f, _f, _i, _f, C.POINTER(_f)]),
     "d3f_unet_train_step": (_i, [_p, _p, _f, _f, _f, _p, _i, _p]),
+    "d3f_unet_set_bn_sync": (_i, [_p, _p, _p, _i]),
     "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
     "d3f_unet_export_shape": (_i, [_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "d3f_conv_upsample_folded": (_i, [_i, _p]),
@@ -87,6 +88,9 @@ PROTOTYPES = {
     "d3f_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p]),
     "d3f_ema_lerp": (_i, [_p, _p, _i64, _f, _p]),
 }
+
+# d3f_allreduce_fn: int (*)(void* ctx, float* data, int64_t count, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
 

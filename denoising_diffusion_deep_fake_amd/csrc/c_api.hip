@@ -324,6 +324,11 @@ int d3f_unet_train_step(d3f_unet_t h, const d3f_step_buffers* b, float lam, floa
   a.lam = lam; a.lo = input_min; a.hi = input_max;
   return h->e.train_step(a, workspace, use_graph, (hipStream_t)stream);
 }
+int d3f_unet_set_bn_sync(d3f_unet_t h, d3f_allreduce_fn fn, void* ctx, int world_size) {
+  D3F_CHECK(h && (fn == nullptr || world_size >= 1), "unet_set_bn_sync: arguments");
+  h->e.set_bn_sync(fn, ctx, world_size);
+  return 0;
+}
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream) {
   D3F_CHECK(h && name && workspace && out_nchw, "unet_export: null argument");
   return h->e.export_tensor(name, workspace, out_nchw, (hipStream_t)stream);

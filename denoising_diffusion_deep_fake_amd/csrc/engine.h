@@ -128,6 +128,13 @@ class UnetEngine {
     float lam, lo, hi;
   };
   int train_step(const StepArgs& a, void* ws, int use_graph, hipStream_t s) const;
+  // Optional synchronised BatchNorm statistics across data-parallel ranks (SURVEY.md 8e "optional SyncBN": makes
+  // N x bs numerically one process with batch N*bs).  fn sum-all-reduces `count` floats of the workspace in place,
+  // ordered on `stream`; it is called once per BatchNorm layer in the forward pass (the per-tile (sum, sum of squares)
+  // partials) and once in the backward pass (the (sum dz, sum dz*xhat) partials); the finalize kernels then divide by
+  // rows * world.  dgamma / dbeta stay LOCAL sums (the gradient all-reduce adds them up like every other gradient).
+  typedef int (*AllReduceFn)(void* ctx, float* data, int64_t count, void* stream);
+  void set_bn_sync(AllReduceFn fn, void* ctx, int world) { bn_sync_fn_ = fn; bn_sync_ctx_ = ctx; bn_sync_world_ = world > 0 ? world : 1; }
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
   int export_shape(const char* name, int32_t dims[3]) const;
 
@@ -206,6 +213,9 @@ class UnetEngine {
   int wait_for_packed_weights(hipStream_t s) const;
   mutable hipStream_t gstream_ = nullptr;
   mutable GraphSlot g_predict_, g_eval_;
+  AllReduceFn bn_sync_fn_ = nullptr;
+  void* bn_sync_ctx_ = nullptr;
+  int bn_sync_world_ = 1;
   int train_step_launches(const StepArgs& a, void* ws, hipStream_t s) const;
   mutable hipGraphExec_t g_step_ = nullptr;
   mutable StepArgs g_step_key_{};

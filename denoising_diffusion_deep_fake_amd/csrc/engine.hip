@@ -736,7 +736,13 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
       if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
       const long rows = (long)B * u.Ho * u.Wo;  // (p.M counts one output-parity class for a folded layer)
-      if (u.apply && bn_fused_finalize_ok(dtype, p.stat_rows, u.Cout)) {
+      const bool sync = bn_sync_fn_ != nullptr;
+      if (sync) {  // statistics over every rank's batch: the partial rows are summed across ranks in place
+        if (int rc = bn_sync_fn_(bn_sync_ctx_, p.stats, (int64_t)p.stat_rows * u.CoutPad * 2, (void*)s))
+          return set_error(rc, "BatchNorm statistics all-reduce failed in the forward pass (%s)", u.bn_name.c_str());
+      }
+      const long count = rows * (sync ? bn_sync_world_ : 1);
+      if (!sync && u.apply && bn_fused_finalize_ok(dtype, p.stat_rows, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip): one launch instead of two
         if (int rc = bn_finalize_apply_launch(dtype, p.stats, p.stat_rows, u.Cout, u.CoutPad, rows, params_ + u.g_off,
                                               params_ + u.b_off, 1e-5f, 0.1f, bnstats + u.rm_off, bnstats + u.rv_off,
@@ -748,7 +754,7 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
           return rc;
         continue;
       }
-      if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, rows,
+      if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, count,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
                                       coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s))
@@ -1127,7 +1133,23 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
                                                u.Cout, s, msc, msf)) {
         return rc;
       }
-      if (!skip_b && bn_fused_finalize_ok(dtype, nb, u.Cout)) {
+      const bool sync = bn_sync_fn_ != nullptr && !skip_b;
+      if (sync) {
+        // synchronised statistics: dgamma / dbeta from the LOCAL sums (they are summed over ranks with the other
+        // gradients), the coefficients of dy from the sums over every rank's batch
+        if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd, grads + u.g_off,
+                                            grads + u.b_off, 0, k, s))
+          return rc;
+        if (int rc = bn_sync_fn_(bn_sync_ctx_, bnpart, (int64_t)nb * u.Cout * 2, (void*)s))
+          return set_error(rc, "BatchNorm statistics all-reduce failed in the backward pass (%s)", u.bn_name.c_str());
+        if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows * bn_sync_world_, params_ + u.g_off, invstd, nullptr,
+                                            nullptr, 0, k, s))
+          return rc;
+        if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
+                                         op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
+                                         u.Cout, s, msc, msf))
+          return rc;
+      } else if (!skip_b && bn_fused_finalize_ok(dtype, nb, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip)
         if (int rc = bn_bwd_finalize_apply_launch(dtype, bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,
                                                   grads + u.g_off, grads + u.b_off, 0, k, G(op.dA), amask, T(u.y), dy,

@@ -79,10 +79,13 @@ class BucketAllReducer:
 class DataParallel:
     """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
 
-    def __init__(self, model, optimizer, group=None):
+    def __init__(self, model, optimizer, group=None, sync_batchnorm=False):
         self.model, self.optimizer = model, optimizer
         self.reducer = BucketAllReducer(group)
         self.world_size = self.reducer.world_size
+        if self.world_size > 1 and sync_batchnorm:
+            # pytorch_lightning's Trainer(sync_batchnorm=True): batch statistics over every rank's images
+            model.set_sync_batchnorm(True if group is None else group, self.world_size)
         if self.world_size > 1:
             model.prepare()
             dist.broadcast(model.flat_params, src=0, group=group)

@@ -212,7 +212,7 @@ def optimizer_steps(model, optimizers, opt_params, batch, batch_idx, takes_idx, 
 class Trainer:
     def __init__(self, max_epochs=1, max_steps=-1, callbacks=None, log_every_n_steps=50, gpus=None,
                  accelerator=None, devices=None, default_root_dir="lightning_logs", flush_every=100,
-                 enable_checkpointing=True, limit_train_batches=None, limit_val_batches=None):
+                 enable_checkpointing=True, limit_train_batches=None, limit_val_batches=None, sync_batchnorm=False):
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.callbacks = list(callbacks or [])
         self.log_every_n_steps = log_every_n_steps
@@ -221,6 +221,7 @@ class Trainer:
         self.enable_checkpointing = enable_checkpointing
         self.limit_train_batches = limit_train_batches
         self.limit_val_batches = limit_val_batches
+        self.sync_batchnorm = sync_batchnorm  # Lightning's flag: BatchNorm statistics over all ranks (default: per GPU)
         self.global_step = 0
         self.current_epoch = 0
         self.logger = None
@@ -349,7 +350,7 @@ class Trainer:
         for opt in self.optimizers:
             mod = getattr(opt, "module", None)
             if mod is not None:
-                dist_utils.DataParallel(mod, opt)
+                dist_utils.DataParallel(mod, opt, sync_batchnorm=self.sync_batchnorm)
         takes_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
         # independent optimizer steps on their own streams (the module decides: LitModule.optimizer_streams)

@@ -106,6 +106,7 @@ class _Engine:
         if os.environ.get("D3F_POISON_WORKSPACE"):  # test hook: any read-before-write shows up as NaN
             self.workspace.fill_(0xFF)
         self.packed_version = None
+        self._bn_cb = None
         self._side = False    # not asked yet
         self.serial = 0       # bumped by every forward that overwrites this workspace
         self.in_use = False   # a recorded autograd graph still needs this workspace's activations
@@ -117,6 +118,30 @@ class _Engine:
             b, e = C.c_int64(), C.c_int64()
             check(L.d3f_unet_segment_range(self.h, s, C.byref(b), C.byref(e)))
             self.seg_ranges.append((b.value, e.value))
+
+    def set_bn_sync(self, group, world_size):
+        """install (group given) or remove (None) the BatchNorm statistics all-reduce of this plan: the C engine calls
+        back with a pointer into this workspace, the callback sums it over the ranks of `group` on the current stream"""
+        L = _lib.lib()
+        if group is None:
+            check(L.d3f_unet_set_bn_sync(self.h, None, None, 1))
+            self._bn_cb = None
+            return
+        import torch.distributed as dist
+        ws = self.workspace
+        base = ws.data_ptr()
+
+        def allreduce(ctx, data, count, stream):
+            try:
+                off = int(data) - base
+                view = ws[off:off + 4 * int(count)].view(torch.float32)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=None if group is True else group)
+                return 0
+            except Exception as e:  # surfaces as the engine's error return (a raise cannot cross the C frame)
+                self._bn_err = e
+                return -3
+        self._bn_cb = _lib.ALLREDUCE_FN(allreduce)  # kept alive with the engine
+        check(L.d3f_unet_set_bn_sync(self.h, C.cast(self._bn_cb, C.c_void_p), None, int(world_size)))
 
     def side_stream(self, device):
         """the engine's weight-gradient stream as a torch stream (None when the engine runs everything on the caller's
@@ -222,7 +247,8 @@ class Unet(nn.Module):
     # -- runtime state that must not be deep-copied / pickled ------------------------------------
     def _init_runtime_state(self):
         self.__dict__["_rt"] = {"flat": None, "flat_grad": None, "flat_bn": None, "flat_nbt": None,
-                                "engines": {}, "table": None, "dirty": True, "grad_sync": None, "params": None}
+                                "engines": {}, "table": None, "dirty": True, "grad_sync": None, "params": None,
+                                "bn_sync": None}
 
     def __deepcopy__(self, memo):
         rt = self.__dict__.pop("_rt")
@@ -337,6 +363,22 @@ class Unet(nn.Module):
         self._ensure_flat(device)
         return self
 
+    def set_sync_batchnorm(self, group=True, world_size=None):
+        """Synchronised BatchNorm statistics over the ranks of `group` (True: the default process group; None: off = the
+        default, per-GPU statistics -- what Lightning DDP does with the reference's Trainer flags).
+        With it on, N ranks x bs are numerically one process with batch N*bs: every train-mode BatchNorm layer
+        all-reduces its statistics in the forward pass and its two gradient sums in the backward pass (2 x 46 small
+        collectives per step -- latency-bound, use it when batch statistics over bs/GPU images are too noisy)."""
+        import torch.distributed as dist
+        if group is not None:
+            if not dist.is_initialized():
+                raise D3FError("set_sync_batchnorm needs an initialised torch.distributed process group")
+            world_size = world_size or dist.get_world_size(None if group is True else group)
+        self._rt["bn_sync"] = None if group is None else (group, int(world_size))
+        for pool in self._rt["engines"].values():
+            for eng in pool:
+                eng.set_bn_sync(*(self._rt["bn_sync"] or (None, 1)))
+
     def set_grad_sync(self, fn):
         """fn(segment_index, flat_grad_slice) is called as soon as a gradient bucket is final
         (data-parallel all-reduce overlap); None disables."""
@@ -358,6 +400,8 @@ class Unet(nn.Module):
             raise D3FError(f"{len(pool)} forward passes of shape {(B, H, W)} are waiting for their backward pass; "
                            f"run inference-only forwards under torch.no_grad()")
         eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device)
+        if self._rt.get("bn_sync"):
+            eng.set_bn_sync(*self._rt["bn_sync"])
         pool.append(eng)
         return eng
 

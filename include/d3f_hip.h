@@ -147,6 +147,14 @@ typedef struct d3f_step_buffers {
 int d3f_adam_coefficients(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float coef[8]);
 int d3f_unet_train_step(d3f_unet_t h, const d3f_step_buffers* buffers, float lambda, float input_min, float input_max,
                         void* workspace, int use_graph, void* stream);
+/* Optional synchronised BatchNorm (what pytorch_lightning's Trainer(sync_batchnorm=True) would add to the
+ * reference's Trainer(gpus=1) at d3f/train_deep_fake/start_training.py:43-48): with a callback installed, every
+ * train-mode BatchNorm takes its batch statistics -- and the two sums of its backward pass -- over ALL ranks' batches.
+ * fn must sum-all-reduce `count` floats at `data` (a region of the workspace handed to forward / backward) in place,
+ * ordered on `stream`, and return 0; it is called from inside d3f_unet_forward / d3f_unet_backward, once per BatchNorm
+ * layer each.  fn == NULL: per-GPU statistics (the default).  The fused finalize kernels are bypassed in this mode. */
+typedef int (*d3f_allreduce_fn)(void* ctx, float* data, int64_t count, void* stream);
+int d3f_unet_set_bn_sync(d3f_unet_t h, d3f_allreduce_fn fn, void* ctx, int world_size);
 /* debugging / tests: copy an internal activation ("<conv name>:y" raw conv output, ":a" post
  * BN+ReLU, ":da" its gradient) to NCHW f32 */
 int d3f_unet_export(d3f_unet_t h, const char* name, const void* workspace, float* out_nchw, void* stream);

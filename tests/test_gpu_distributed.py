@@ -203,3 +203,68 @@ def test_bench_self_launch_two_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["config"]["parallelism"] == "dp2"
     assert res["value"] > 0 and res["roofline"]["frac"] is not None and res["roofline"]["launches"] > 0
+
+
+def _syncbn_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.distributed import DataParallel, init_process_group
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    init_process_group("gloo")
+    torch.cuda.set_device(0)
+    B, S = 4, 64
+    half = B // world
+    x = synthetic_face_crops(B, S, seed=60, device="cuda")        # the GLOBAL batch, identical on both ranks
+    tgt = synthetic_face_crops(B, S, seed=61, device="cuda")
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    # reference: ONE process, the whole batch, ordinary (local = global) statistics
+    torch.manual_seed(9)
+    ref = Unet("resnet34", None, 3, 3, None).cuda().train()
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    pred_ref = ref(x)
+    _, gout = ops.mse_ssim_loss(pred_ref.detach(), tgt)
+    pred_ref.backward(gout)
+    g_ref = ref.flat_grads.clone()
+    bn_ref = ref.flat_bn_stats.clone()
+
+    # two ranks, half the batch each, synchronised statistics; upstream gradient = this rank's rows of the same gout
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    net.load_state_dict(state)
+    opt = FusedAdam(net.parameters(), lr=0.01, module=net)
+    DataParallel(net, opt, sync_batchnorm=True)
+    sl = slice(rank * half, (rank + 1) * half)
+    pred = net(x[sl].contiguous())
+    pred.backward(gout[sl].contiguous())
+    opt.before_step()                      # join the bucket all-reduces (sum over ranks)
+    torch.cuda.synchronize()
+    ret[rank] = dict(pred=rel(pred, pred_ref[sl]), grad=rel(net.flat_grads, g_ref), bn=rel(net.flat_bn_stats, bn_ref),
+                     worst=max(rel(p.grad, q.grad) for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters())
+                               if q.grad.abs().max() > 0))
+    # and WITHOUT synchronisation the halves see different statistics: the outputs must differ (the test has teeth)
+    net.set_sync_batchnorm(None)
+    with torch.no_grad():
+        ret[rank]["pred_unsynced"] = rel(net(x[sl].contiguous()), pred_ref[sl])
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_one_process():
+    """Optional SyncBN (pytorch_lightning's Trainer(sync_batchnorm=True)): two ranks x bs 2 with the
+    BatchNorm statistics all-reduced through d3f_unet_set_bn_sync must be numerically ONE process with bs 4 -- outputs,
+    running statistics and (summed over ranks) every parameter gradient -- up to the summation order."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_syncbn_worker, (world, _free_port(), ret), world, seconds=200)
+    for r in range(world):
+        o = ret[r]
+        assert o["pred"] < 2e-5, o
+        assert o["bn"] < 1e-5, o
+        assert o["grad"] < 2e-4 and o["worst"] < 2e-3, o   # flat / worst single tensor (mask flips at rounding level)
+        assert o["pred_unsynced"] > 1e-2, o
