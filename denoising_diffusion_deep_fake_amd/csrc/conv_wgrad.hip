@@ -515,7 +515,13 @@ bool wgrad_class_applies(const WgradParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_WGRAD_CLASS") != nullptr;  // debugging knob: nine taps through the up-sampling
   if (off || !p.shift0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
   if (p.Ho != p.Hv || p.Wo != p.Wv || p.H0s * 2 != p.Hv || p.W0s * 2 != p.Wv) return false;
-  if (getenv("D3F_NO_PATCH_WGRAD") == nullptr && wgrad_patch_variant(p, dtype)) return false;
+  if (getenv("D3F_NO_PATCH_WGRAD") == nullptr) {
+    // the narrow decoder layers (persistent patch kernel, conv_wgrad_patch.hip): its class form takes variants 1 and 3
+    // with whole 32-channel slices per source (D3F_NO_PATCH_CLASS: the nine-tap patch kernel, for the A/B)
+    const int v = wgrad_patch_variant(p, dtype);
+    static const bool no_pc = getenv("D3F_NO_PATCH_CLASS") != nullptr;
+    if (v) return !no_pc && (v == 1 || v == 3) && (p.C0 % 32) == 0 && (p.C1 % 32) == 0 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0;
+  }
   const WTile t = pick_wtile(p, dtype);
   return (t.bm == 64 || t.kp == 128) && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
 }
@@ -545,12 +551,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   p.Hc = p.cls ? p.H0s : p.Ho;
   p.Wc = p.cls ? p.W0s : p.Wo;
   p.Mi = p.B * p.Hc * p.Wc;
-  if (p.part != WG_WHOLE) {
-    D3F_CHECK(group == 1 && wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
-    p.patch = 0;
-  } else {
-    p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
-  }
+  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
+  if (p.part != WG_WHOLE) D3F_CHECK(group == 1 && wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
   D3F_CHECK(group == 1 || (p.patch == 0 && p.C1 == 0), "wgrad: only plain single-source layers are grouped");
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
     int gx, gy;
@@ -584,7 +586,6 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
 }
 
 size_t wgrad_partial_floats(const WgradParams& p) {
-  if (p.patch) return (size_t)p.splits * p.Cout * p.KH * p.KW * (p.C0 + p.C1);
   return (size_t)p.splits * p.Cout * p.slab_taps * p.slab_cin;
 }
 
@@ -761,9 +762,9 @@ int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void*
     w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = partial;
     if (int rc = wgrad_launch(w, dtype, stream)) return rc;
     const int c_off = w.ci_base;
-    const int creal = std::max(0, std::min(w.patch ? w.C0 + w.C1 : w.slab_cin, CinReal - c_off));
-    if (int rc = wgrad_reduce_batch_add(tb, partial, w.splits, w.Cout, CoutReal, w.patch ? w.C0 + w.C1 : w.slab_cin, creal,
-                                        CinReal, c_off, w.KH, w.KW, w.cls, dw))
+    const int creal = std::max(0, std::min(w.slab_cin, CinReal - c_off));
+    if (int rc = wgrad_reduce_batch_add(tb, partial, w.splits, w.Cout, CoutReal, w.slab_cin, creal, CinReal, c_off, w.KH,
+                                        w.KW, w.cls, dw))
       return rc;
     partial += (wgrad_partial_floats(w) + 63) / 64 * 64;
   }
@@ -782,7 +783,7 @@ int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, co
     const int c_off = w.ci_base;
     // real channels of this part: channel padding only ever sits at the end of the concatenation
     const int creal = std::max(0, std::min(w.slab_cin, CinReal - c_off));
-    if (int rc = wgrad_reduce_launch_part(partial, w.splits, w.Cout, CoutReal, w.patch ? w.C0 + w.C1 : w.slab_cin, creal,
+    if (int rc = wgrad_reduce_launch_part(partial, w.splits, w.Cout, CoutReal, w.slab_cin, creal,
                                           CinReal, c_off, w.KH, w.KW, w.cls, dst, stream))
       return rc;
   }

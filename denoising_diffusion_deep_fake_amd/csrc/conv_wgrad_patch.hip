@@ -64,10 +64,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & (MT - 1);       // column / row inside the MFMA tile
   const int lg = lane / MT;             // pixel group inside a k-step: 0..KSTEP-1
-  const int Cin = p.C0 + p.C1;
+  // channels this launch covers: all of them, or one source's (WgradParams::part: WG_SKIP = source 1 only); its slabs
+  // are slab_cin wide and hold launch-local channel indices
+  const int Cin = p.slab_cin;
   const int ci_slices = Cin / CI_T;
   const int slice = blockIdx.y;
-  const int ci0 = (slice % ci_slices) * CI_T, co0 = (slice / ci_slices) * CO_T;
+  const int cil0 = (slice % ci_slices) * CI_T;           // launch-local
+  const int ci0 = p.ci_base + cil0, co0 = (slice / ci_slices) * CO_T;
   const bool from0 = ci0 < p.C0;
   const int Cs = from0 ? p.C0 : p.C1;
   const int sh = from0 ? p.shift0 : 0;
@@ -196,8 +199,153 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
       const float s = (red[e] + red[MT * MT + e]) + (red[2 * MT * MT + e] + red[3 * MT * MT + e]);
       const int co = co0 + e / MT;
       const int n = j * MT + (e % MT);
-      const int tap = n / CI_T, ci = ci0 + (n - tap * CI_T);
+      const int tap = n / CI_T, ci = cil0 + (n - tap * CI_T);
       if (co < p.Cout && tap < taps) slab[((long)co * taps + tap) * Cin + ci] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Class form (WgradParams::cls) of the same kernel for conv(cat(upsample2x(x), skip)): the gradient for the channels of
+// the up-sampled source x.  Inside output-parity class (py, px) the nine taps on the up-sampled operand touch a 2x2
+// neighbourhood of the LOW-resolution x (conv_wgrad.hip, WG_CLASS), so instead of 9 taps over every pixel a workgroup
+// runs 2 classes (its py, both px) x 2x2 folded taps over the pixels of those classes: 8 accumulator column groups for
+// half of the tile's pixels -- 4/9 of the MACs.  blockIdx.y = (py, co slice, ci slice): the workgroup stages only the
+// tile rows of parity py (half the dY tile) and the (TH/2 + 2) x (TW/2 + 2) low-resolution patch; wave w sweeps tile
+// row 2w + py.  Slabs: [split][Cout][16 folded taps][slab_cin], tap = ((py*2 + px)*2 + a)*2 + b; the two py workgroups
+// of a slab write disjoint taps; wgrad_reduce_kernel<true> folds them into the 3x3 gradient.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int MT, int CI_T, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradParams p) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int CO_T = MT;
+  constexpr int RH = PT_TH / 2;                   // tile rows of one parity: one per wave
+  static_assert(RH == 4, "one tile row of the parity per wave");
+  constexpr int PHL = PT_TH / 2 + 2, PWL = TW / 2 + 2;  // low-resolution patch with its halo
+  constexpr int KSTEP = (MT == 32) ? 2 : 4;       // pixels per MFMA
+  constexpr int NCT = CI_T / MT;                  // column tiles per folded tap
+  constexpr int NNT = 8 * NCT;                    // (px, a, b) x column tiles
+  static_assert(CI_T % MT == 0, "whole column tiles per folded tap");
+  constexpr int LXS = (MT == 16 ? CI_T + 16 : CI_T + 4);
+  constexpr int LYS = (MT == 32) ? CO_T + 4 : CO_T;
+  constexpr int XF = PHL * PWL * LXS, YF = RH * TW * LYS;
+  constexpr int RED = 4 * MT * MT;
+  constexpr int LDS_F = (XF + YF > RED) ? XF + YF : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+  float* Xs = lds;
+  float* Ys = lds + XF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & (MT - 1);
+  const int lg = lane / MT;
+  const int Cin = p.slab_cin;                     // = C0: the class form covers source 0
+  const int ci_slices = Cin / CI_T;
+  int slice = blockIdx.y;
+  const int py = slice & 1;
+  slice >>= 1;
+  const int ci0 = (slice % ci_slices) * CI_T, co0 = (slice / ci_slices) * CO_T;
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.src0, p.src0_bytes);
+
+  typename PAcc<MT>::T acc[NNT];
+#pragma unroll
+  for (int j = 0; j < NNT; ++j)
+#pragma unroll
+    for (int r = 0; r < PAcc<MT>::N; ++r) acc[j][r] = 0.f;
+
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + PT_TH - 1) / PT_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  constexpr int VX = CI_T / VE, VY = CO_T / VE;
+  constexpr int NVX = (PHL * PWL * VX + 255) / 256, NVY = (RH * TW * VY + 255) / 256;
+  uint4 rxv[NVX], ryv[NVY];
+  auto issue_loads = [&](int t) {
+    const int b = t / (tiles_y * tiles_x);
+    const int tr = t - b * tiles_y * tiles_x;
+    const int oy0 = (tr / tiles_x) * PT_TH, ox0 = (tr % tiles_x) * TW;
+    const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;  // low-resolution patch origin
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VX, cv = v - pix * VX;
+      const int yy = pix / PWL, xx = pix - yy * PWL;
+      const int iy = ly0 + yy, ix = lx0 + xx;
+      const bool ok = v < PHL * PWL * VX && (unsigned)iy < (unsigned)p.H0s && (unsigned)ix < (unsigned)p.W0s;
+      const int gp = (b * p.H0s + iy) * p.W0s + ix;
+      rxv[i] = buf_load16(rx, ok ? (unsigned)(gp * p.C0 + ci0 + cv * VE) * (unsigned)sizeof(T) : BUF_OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VY, cv = v - pix * VY;
+      const int r = pix / TW, x = pix - r * TW;
+      const int oy = oy0 + 2 * r + py, ox = ox0 + x;
+      const int co = co0 + cv * VE;
+      const bool ok = v < RH * TW * VY && oy < p.Ho && ox < p.Wo && co < p.Cout;
+      ryv[i] = buf_load16(rdy, ok ? (unsigned)(((b * p.Ho + oy) * p.Wo + ox) * p.Cout + co) * (unsigned)sizeof(T) : BUF_OOB);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VX, cv = v - pix * VX;
+      if (v < PHL * PWL * VX) patch_store_f32<T>(&Xs[pix * LXS + cv * VE], rxv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v / VY, cv = v - pix * VY;
+      if (v < RH * TW * VY) patch_store_f32<T>(&Ys[pix * LYS + cv * VE], ryv[i]);
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) issue_loads(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) issue_loads(t + gridDim.x);
+    // wave w: tile row 2w + py -> low-resolution row j = w (tile-local); source row of folded tap a: j + a - 1 + py,
+    // i.e. patch row w + a + py; source column of (px, b) for the pixel at low-resolution column i: i + b - 1 + px,
+    // i.e. patch column i + b + px
+    const float* __restrict__ yrow = Ys + (wave * TW) * LYS + lc;
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+#pragma unroll
+      for (int xs = 0; xs < (TW / 2) / KSTEP; ++xs) {
+        const int il = lg + xs * KSTEP;                      // low-resolution column of this lane's pixel (tile-local)
+        const float a = yrow[(2 * il + px) * LYS];
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            const float* __restrict__ xb = Xs + ((wave + fa + py) * PWL + il + fb + px) * LXS + lc;
+#pragma unroll
+            for (int jc = 0; jc < NCT; ++jc) pmma<MT>(acc[((px * 2 + fa) * 2 + fb) * NCT + jc], a, xb[jc * MT]);
+          }
+      }
+    }
+  }
+
+  // ---- sum the four waves' partial accumulators, one column tile at a time -------------------------
+  float* __restrict__ slab = p.partial + (long)blockIdx.x * p.Cout * 16 * Cin;
+  float* red = lds;
+#pragma unroll
+  for (int j = 0; j < NNT; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PAcc<MT>::N; ++r) {
+      const int co_l = (MT == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * lg) : (4 * lg + r);
+      red[(wave * MT + co_l) * MT + lc] = acc[j][r];
+    }
+    __syncthreads();
+    const int f8 = j / NCT, jc = j - f8 * NCT;           // f8 = (px*2 + a)*2 + b
+    const int tap = py * 8 + f8;                          // ((py*2 + px)*2 + a)*2 + b
+    for (int e = tid; e < MT * MT; e += 256) {
+      const float s = (red[e] + red[MT * MT + e]) + (red[2 * MT * MT + e] + red[3 * MT * MT + e]);
+      const int co = co0 + e / MT;
+      const int ci = ci0 + jc * MT + (e % MT);
+      if (co < p.Cout) slab[((long)co * 16 + tap) * Cin + ci] = s;
     }
   }
 }
@@ -225,10 +373,10 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
 }
 
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
-  const int cin = p.C0 + p.C1;
+  const int cin = p.part == WG_WHOLE ? p.C0 + p.C1 : p.part == WG_CLASS ? p.C0 : p.C1;  // channels of this launch
   const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : variant == 5 ? 8 : 4;
   const int co_t = (variant == 3 || variant == 4 || variant == 5) ? 32 : 16;
-  const int slices = (cin / ci_t) * cdiv(p.Cout, co_t);
+  const int slices = (cin / ci_t) * cdiv(p.Cout, co_t) * (p.part == WG_CLASS ? 2 : 1);  // class form: x 2 row parities
   const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
   int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
   if (g > tiles) g = tiles;
@@ -253,6 +401,19 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
   wgrad_patch_grid(p, variant, &gx, &gy);
   D3F_CHECK(p.splits == gx, "wgrad patch: params were not planned (splits %d vs %d)", p.splits, gx);
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  if (p.cls) {
+    D3F_CHECK((variant == 1 || variant == 3) && p.slab_cin == p.C0 && (p.C0 % 32) == 0 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0,
+              "wgrad patch: class form needs variant 1 or 3 and whole 32-channel slices of source 0");
+    if (dtype == D3F_F32) {
+      if (variant == 1) hipLaunchKernelGGL((conv_wgrad_patch_cls_kernel<float, 16, 32, 16>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_patch_cls_kernel<float, 32, 32, 16>), grid, block, 0, stream, p);
+    } else {
+      if (variant == 1) hipLaunchKernelGGL((conv_wgrad_patch_cls_kernel<bf16_t, 16, 32, 16>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_patch_cls_kernel<bf16_t, 32, 32, 16>), grid, block, 0, stream, p);
+    }
+    D3F_HIP(hipGetLastError());
+    return 0;
+  }
   if (variant == 4) {
     D3F_CHECK(dtype == D3F_F32, "wgrad patch: stem variant 4 is the f32 one");
     hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
