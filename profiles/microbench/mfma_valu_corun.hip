@@ -17,13 +17,15 @@
 #include <cstdlib>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 // ROLE: which half of the workgroup's waves are the matrix waves (0: waves 0-3 = the older ones, 1: waves 4-7).  The
 // issue arbiter favours the oldest wave, so both loops are timed (matrix: wave 0 or 4, partner: the other) and every
 // combination is run alone and together: if the two kinds of work shared an execution resource, at least one of the two
 // loops would take longer together than alone.
-template <int MODE, int ROLE>
+// BF: the matrix waves stream v_mfma_f32_32x32x16_bf16 (the XDL matrix core) instead of the fp32 MFMA
+template <int MODE, int ROLE, bool BF = false>
 __global__ __launch_bounds__(512) void bench(float* out, long long* ticks, int n, int partner_iters, const float* in) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -36,11 +38,23 @@ __global__ __launch_bounds__(512) void bench(float* out, long long* ticks, int n
     if (n > 0) {
       f32x16 acc = {0}, acc2 = {0};
       const float a0 = in[tid], b0 = in[tid + 512];
-      for (int it = 0; it < n; ++it) {
+      if constexpr (BF) {
+        bf16x8 va, vb;
+        for (int k = 0; k < 8; ++k) { va[k] = (__bf16)in[tid + k]; vb[k] = (__bf16)in[tid + 8 + k]; }
+        for (int it = 0; it < n; ++it) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc2, 0, 0, 0);
+          for (int q = 0; q < 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, va, acc2, 0, 0, 0);
+          }
+        }
+      } else {
+        for (int it = 0; it < n; ++it) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc2, 0, 0, 0);
+          }
         }
       }
       for (int r = 0; r < 16; ++r) res += acc[r] + acc2[r];
@@ -94,10 +108,10 @@ __global__ __launch_bounds__(512) void bench(float* out, long long* ticks, int n
   out[blockIdx.x * 512 + tid] = res;
 }
 
-template <int MODE, int ROLE>
+template <int MODE, int ROLE, bool BF = false>
 static void run(const char* what, int n, int partner_iters, float* out, long long* ticks, const float* in) {
   const int wgs = 256;
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((bench<MODE, ROLE>), dim3(wgs), dim3(512), 0, 0, out, ticks, n, partner_iters, in);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((bench<MODE, ROLE, BF>), dim3(wgs), dim3(512), 0, 0, out, ticks, n, partner_iters, in);
   CK(hipDeviceSynchronize());
   std::vector<long long> h(2 * wgs);
   CK(hipMemcpy(h.data(), ticks, 2 * wgs * sizeof(long long), hipMemcpyDeviceToHost));
@@ -136,5 +150,12 @@ int main() {
   trio<2>("fp32 v_fma chains", n, 15000, out, ticks, in);
   trio<4>("ds_read_b128 + 4 VALU each", n, 6000, out, ticks, in);
   trio<3>("second MFMA loop", n, 4000, out, ticks, in);
+  // the same question for the bf16 matrix core (32x32x16: 8 passes = 32 cycles per instruction)
+  const int nb = 8000;
+  run<1, 0, true>("bf16 matrix waves alone", nb, 0, out, ticks, in);
+  run<1, 0, true>("bf16 matrix + integer VALU chains, matrix older", nb, 15000, out, ticks, in);
+  run<1, 1, true>("bf16 matrix + integer VALU chains, matrix younger", nb, 15000, out, ticks, in);
+  run<2, 0, true>("bf16 matrix + fp32 v_fma chains, matrix older", nb, 15000, out, ticks, in);
+  run<4, 0, true>("bf16 matrix + ds_read_b128 + 4 VALU, matrix older", nb, 6000, out, ticks, in);
   return 0;
 }
