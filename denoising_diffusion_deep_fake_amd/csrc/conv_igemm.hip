@@ -1403,7 +1403,7 @@ static bool forced_tile(int* bm, int* bn, int* sk) {
   return on;
 }
 
-static ConvTile pick_tile(const ConvParams& p, bool x3) {
+static ConvTile pick_tile(const ConvParams& p, bool x3, bool bf16 = false) {
   const int co = p.Cout;
   int fbm, fbn, fsk;
   if (forced_tile(&fbm, &fbn, &fsk) && co >= 64) return {fbm, fbn};
@@ -1421,7 +1421,10 @@ static ConvTile pick_tile(const ConvParams& p, bool x3) {
   // to 384; 2 = as 1 with 64x32 in between; 3 (default) = 32x32 all the way to 384.  Measured in one call (r02_v):
   // 3 is 1.2 % faster per step than 1 -- this kernel gets slower (smaller tiles) but the 27 slab-reduce launches
   // per step and their slab traffic leave the caller's stream
-  static const int ksplit_mode = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : 3;
+  // bf16 storage defaults to 2: its MFMA work is a quarter, the 32x32 tile's L2 -> LDS traffic (302 MB per layer3
+  // launch) is what it waits for -- r03 sweep 4.62 / 4.58 / 4.42 / 4.53 ms per step for modes 0 / 1 / 2 / 3
+  static const int ksplit_knob = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : -1;
+  const int ksplit_mode = ksplit_knob >= 0 ? ksplit_knob : (bf16 ? 2 : 3);
   if (!x3 && ksplit_mode > 0 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
     const long b64 = blocks(64, 64);
     if (b64 < 192 || (b64 < 384 && ksplit_mode == 3)) return {32, 32};
@@ -1484,7 +1487,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
     conv_patch_plan(p);
     return 0;
   }
-  const ConvTile t = pick_tile(p, dtype == D3F_F32X3);
+  const ConvTile t = pick_tile(p, dtype == D3F_F32X3, dtype == D3F_BF16);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
   // tuning knob D3F_XCD_SWIZZLE: letters i (this kernel) / w (weight gradient).  Measured: the remap cuts this
@@ -1535,7 +1538,7 @@ static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
 }
 
 template <typename T, bool X3> static int launch_t(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const ConvTile t = pick_tile(p, X3);
+  const ConvTile t = pick_tile(p, X3, sizeof(T) == 2 && !X3);
   D3F_CHECK(p.tiles_m == cdiv(p.M, t.BM) && p.tiles_n == cdiv(p.Cout, t.BN),
             "conv: params were not planned (tiles %d,%d)", p.tiles_m, p.tiles_n);
   if (t.BM == 256 && t.BN == 16) return launch_cfg<T, 256, 16, 4, 1, 16, X3>(p, smallc, stream);
