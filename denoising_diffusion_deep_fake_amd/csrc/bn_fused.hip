@@ -32,22 +32,6 @@ bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= max_rows;
 }
 
-// four consecutive channels of one tensor row: 16 bytes (f32) / 8 bytes (bf16) per thread
-template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
-template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
-  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                     __uint_as_float(v.y & 0xffff0000u));
-}
-template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v);
-template <> __device__ __forceinline__ void st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float4& v) {
-  const uint32_t a = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-  const uint32_t b = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-  *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
-}
-
 // sums the partial rows [rows][ld][2] of channels [c0, c0 + 32) in f64: thread (rl = tid / 16, q = tid % 16) owns the
 // float4 q of the slab (channels c0 + 2q, c0 + 2q + 1; sum, second sum each) of rows rl, rl + 16, ...; the 16 row
 // lanes are then added in lane order.  tot[2 * ch + which] for ch < 32.

@@ -54,6 +54,22 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
+// four consecutive elements of a tensor row as fp32: 16 bytes (f32) / 8 bytes (bf16)
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float4& v) {
+  const uint32_t a = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+  const uint32_t b = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
+}
+
 // ---- raw buffer loads: out-of-range lanes read zeros in hardware (no branch, no select) --------
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned BUF_OOB = 0x80000000u;  // every descriptor here covers < 2 GiB
@@ -162,7 +178,7 @@ struct ConvParams {
   const float* bn_coef;
   float* bn_partial;
   const void* bn_a;    // that layer's activation when its ReLU mask cannot be recomputed from y (residual add) or null
-  int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel (conv_patch.hip; filled by plan)
+  int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
 };
 
 struct ConvTile {
@@ -189,7 +205,7 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
 // conv_patch.hip: LDS-patch form of the full-resolution 16-channel 3x3 layers (chosen inside conv_igemm_plan)
 bool conv_patch_applies(const ConvParams& p, int dtype);
 bool conv_stem_applies(const ConvParams& p, int dtype);  // encoder.conv1 (7x7 stride 2, 4 staged channels)
-void conv_patch_plan(ConvParams& p);
+void conv_patch_plan(ConvParams& p, int dtype);
 int conv_patch_launch(const ConvParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------

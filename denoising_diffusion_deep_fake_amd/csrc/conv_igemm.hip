@@ -1484,7 +1484,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
   p.patch = 0;
   if (conv_patch_applies(p, dtype) || conv_stem_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
-    conv_patch_plan(p);
+    conv_patch_plan(p, dtype);
     return 0;
   }
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3, dtype == D3F_BF16);

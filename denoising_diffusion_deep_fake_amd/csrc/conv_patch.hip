@@ -25,34 +25,39 @@ constexpr int CP_PH = 4, CP_PW = 64;  // output tile (rows x columns); 256 rows 
 
 bool conv_patch_applies(const ConvParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_PATCH_CONV") != nullptr;  // debugging knob: the implicit-GEMM path instead
-  if (off || dtype != D3F_F32) return false;
+  if (off || (dtype != D3F_F32 && dtype != D3F_BF16)) return false;
   const bool mode_ok = p.mode == CONV_RAW_STATS || p.mode == CONV_HEAD_NCHW ||
                        (p.mode == CONV_EVAL_FUSED && p.res == nullptr) ||
                        (p.mode == CONV_DGRAD && p.out_c0 == p.Cout && (p.Cout % 4) == 0);
   // C0 == 4: the data gradient of the segmentation head (dY has 3 channels padded to 4, 16 outputs): as an implicit
   // GEMM it ran 110 us in the traced step for 17 MB in / 67 MB out (profiles/r03_z_step_launches.txt)
-  const bool cin_ok = p.C0 == 16 || (p.C0 == 4 && p.mode == CONV_DGRAD);
+  // bf16 storage (round 3): the 16-channel form on v_mfma_f32_16x16x16_bf16, one instruction per tap and fragment
+  const bool cin_ok = p.C0 == 16 || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
          p.shift0 == 0 && p.zi == 0 && p.Cout <= 16 && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
          (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
 
-template <int CIN, int BN>
+template <typename T, int CIN, int BN>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
-  static_assert((CIN == 16 || CIN == 4) && BN == 16, "16 channels (forward / data gradient of decoder block 4, head "
-                                                      "forward) or 4 (data gradient of the head)");
+  constexpr bool BF = sizeof(T) == 2;
+  static_assert((CIN == 16 || (CIN == 4 && !BF)) && BN == 16, "16 channels (forward / data gradient of decoder block 4, "
+                                                               "head forward) or, fp32, 4 (data gradient of the head)");
+  constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte vector
   constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
-  // dwords per staged pixel: 16-byte aligned and such that the fragment reads spread over the banks (CIN 16: +4 pad,
-  // 16-byte reads; CIN 4: stride 12, scalar reads -- 12 * row + k covers the 32 banks over 8 consecutive rows)
-  constexpr int CS = CIN == 16 ? CIN + 4 : 12;
+  // dwords per staged pixel: such that the fragment reads spread over the banks (fp32 CIN 16: +4 pad, 16-byte reads;
+  // CIN 4: stride 12, scalar reads; bf16: 32 B of channels + 8 B pad = 10 dwords -- 10 * row covers the even banks
+  // over 16 rows, the 8-byte fragment reads are conflict-free; the staging stores are 8-byte halves)
+  constexpr int CS = BF ? 10 : (CIN == 16 ? CIN + 4 : 12);
   constexpr int KR = 9 * CIN;        // real k extent
-  // dwords per staged weight row (CIN 16: no pad, 16-byte chunks XOR-swizzled by the row; CIN 4: +4 pad, no swizzle)
-  constexpr int WS = CIN == 16 ? KR : KR + 4;
-  constexpr int CV = CIN / 4;        // 16-byte vectors per pixel
-  constexpr int NPV = PR * PC * CV;  // patch vectors
-  constexpr int NWV = BN * (KR / 4); // weight vectors
+  // dwords per staged weight row (fp32 CIN 16: no pad, 16-byte chunks XOR-swizzled by the row; CIN 4: +4 pad, no
+  // swizzle; bf16: 72 dwords of taps + 2 = 74: the same stride-10-mod-32 pattern over the filter rows)
+  constexpr int WS = BF ? KR / 2 + 2 : (CIN == 16 ? KR : KR + 4);
+  constexpr int CV = CIN / VEC;        // 16-byte vectors per pixel
+  constexpr int NPV = PR * PC * CV;    // patch vectors
+  constexpr int NWV = BN * (KR / VEC); // weight vectors
   constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
   constexpr int BM = PH * PW, LDC = BN + 4, FM = PW / 16;
   constexpr int PATCH_DW = PR * PC * CS > BM * LDC ? PR * PC * CS : BM * LDC;  // the C tile aliases the patch
@@ -77,27 +82,41 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
     const int pr = pix / PC, pc = pix - pr * PC;
     const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
     const bool ok = id < NPV && (unsigned)gy < (unsigned)p.Hv && (unsigned)gx < (unsigned)p.Wv;
-    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * p.Hv + gy) * p.Wv + gx) * CIN + cv * 4) * 4u : BUF_OOB);
+    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * p.Hv + gy) * p.Wv + gx) * CIN + cv * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
 #pragma unroll
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
-    const int row = id / (KR / 4), ch = id - row * (KR / 4);
+    const int row = id / (KR / VEC), ch = id - row * (KR / VEC);
     const bool ok = id < NWV && row < p.CoutPad;
-    wv[i] = buf_load16(rw, ok ? (unsigned)(row * p.w_ld + ch * 4) * 4u : BUF_OOB);
+    wv[i] = buf_load16(rw, ok ? (unsigned)(row * p.w_ld + ch * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
 #pragma unroll
   for (int i = 0; i < NLP; ++i) {
     const int id = tid + 256 * i;
     const int pix = id / CV, cv = id - pix * CV;
-    if (NPV % 256 == 0 || id < NPV) *reinterpret_cast<uint4*>(&P[pix * CS + cv * 4]) = pv[i];
+    if (NPV % 256 == 0 || id < NPV) {
+      if constexpr (BF) {  // 40-byte pixels: two 8-byte stores
+        *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4]) = make_uint2(pv[i].x, pv[i].y);
+        *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4 + 2]) = make_uint2(pv[i].z, pv[i].w);
+      } else {
+        *reinterpret_cast<uint4*>(&P[pix * CS + cv * 4]) = pv[i];
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
-    const int row = id / (KR / 4), ch = id - row * (KR / 4);
-    const int chs = CIN == 16 ? (ch ^ ((row >> 1) & 3)) : ch;
-    if (NWV % 256 == 0 || id < NWV) *reinterpret_cast<uint4*>(&Wl[row * WS + chs * 4]) = wv[i];
+    const int row = id / (KR / VEC), ch = id - row * (KR / VEC);
+    if (NWV % 256 == 0 || id < NWV) {
+      if constexpr (BF) {
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4]) = make_uint2(wv[i].x, wv[i].y);
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4 + 2]) = make_uint2(wv[i].z, wv[i].w);
+      } else {
+        const int chs = CIN == 16 ? (ch ^ ((row >> 1) & 3)) : ch;
+        *reinterpret_cast<uint4*>(&Wl[row * WS + chs * 4]) = wv[i];
+      }
+    }
   }
   __syncthreads();
 
@@ -109,7 +128,23 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   f32x4 acc[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (CIN == 16) {
+  if constexpr (BF) {
+    // bf16: v_mfma_f32_16x16x16_bf16 contracts all 16 channels of a tap at once: lane holds channels 4 fq .. 4 fq + 3
+    // (8 bytes) of its pixel / filter
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const float* Abase = P + (wave * PC + fr) * CS + fq * 2;
+    const float* Bbase = Wl + fr * WS + fq * 2;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const v4s bb = *reinterpret_cast<const v4s*>(Bbase + tap * (CIN / 2));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const v4s a = *reinterpret_cast<const v4s*>(Abase + ((kh * PC + kw) + i * 16) * CS);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bb, acc[i], 0, 0, 0);
+      }
+    }
+  } else if constexpr (CIN == 16) {
     const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
     const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // a tap's four chunks are permuted by the row
 #pragma unroll
@@ -179,12 +214,12 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   auto out_row = [&](int row) { return mrow0 + (long)(row / PW) * p.Wo + (row % PW); };
 
   if (p.mode == CONV_RAW_STATS) {
-    float* __restrict__ out = reinterpret_cast<float*>(p.out0);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
     if (n_ok) {
 #pragma unroll
       for (int i = 0; i < NVEC; ++i) {
         const int row = rv0 + i * RSTEP;
-        *reinterpret_cast<float4*>(out + out_row(row) * p.Cout + n) = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+        st4<T>(out + out_row(row) * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
       }
     }
     if (p.stats != nullptr) {
@@ -215,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
       }
     }
   } else if (p.mode == CONV_EVAL_FUSED) {
-    float* __restrict__ out = reinterpret_cast<float*>(p.out0);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out0);
     if (n_ok) {
       const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
 #pragma unroll
@@ -224,31 +259,31 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
         v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(out + out_row(row) * p.Cout + n) = v;
+        st4<T>(out + out_row(row) * p.Cout + n, v);
       }
     }
   } else {  // CONV_DGRAD, one destination
-    float* __restrict__ o0 = reinterpret_cast<float*>(p.out0);
+    T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
     if (n_ok) {
 #pragma unroll
       for (int i = 0; i < NVEC; ++i) {
         const int row = rv0 + i * RSTEP;
         float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
-        float* dst = o0 + out_row(row) * p.Cout + n;
+        T* dst = o0 + out_row(row) * p.Cout + n;
         if (p.acc0) {
-          const float4 o = *reinterpret_cast<const float4*>(dst);
+          const float4 o = ld4<T>(dst);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           if (p.bn_partial != nullptr) *reinterpret_cast<float4*>(&Cs[row * LDC + cv * 4]) = v;
         }
-        *reinterpret_cast<float4*>(dst) = v;
+        st4<T>(dst, v);
       }
     }
     if (p.bn_partial != nullptr) {
       // fused BatchNorm-backward reduction of the consuming layer (as conv_igemm.hip): 16-byte loads of y (and a) for
       // the thread's own rows, column sums in registers, thread rows added through LDS in order
       const int C = p.Cout;
-      const float* __restrict__ yb = reinterpret_cast<const float*>(p.bn_y);
-      const float* __restrict__ ab = reinterpret_cast<const float*>(p.bn_a);
+      const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+      const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
       if (n_ok) {
         const float4 mu = *reinterpret_cast<const float4*>(p.bn_coef + n), is = *reinterpret_cast<const float4*>(p.bn_coef + C + n);
@@ -259,8 +294,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) {
           const long m = out_row(rv0 + i * RSTEP);
-          yv[i] = *reinterpret_cast<const float4*>(yb + m * C + n);
-          av[i] = ab != nullptr ? *reinterpret_cast<const float4*>(ab + m * C + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          yv[i] = ld4<T>(yb + m * C + n);
+          av[i] = ab != nullptr ? ld4<T>(ab + m * C + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) {
@@ -466,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
 }
 
 // plan: one workgroup per 4 x 64 output tile, one statistics row per tile
-void conv_patch_plan(ConvParams& p) {
+void conv_patch_plan(ConvParams& p, int dtype) {
   if (p.KH == 7) {  // encoder.conv1 form: 8 x 32 tiles, 32 filters per workgroup
     p.patch = 2;
     p.nz = 1;
@@ -478,7 +513,7 @@ void conv_patch_plan(ConvParams& p) {
     p.stat_rows = p.tiles_m;
     return;
   }
-  p.patch = 1;
+  p.patch = dtype == D3F_BF16 ? 3 : 1;  // 3: the bf16-storage instantiation
   p.nz = 1;
   p.splitk = 1;
   p.xcd_swizzle = 0;
@@ -496,10 +531,12 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK(p.patch == 1 && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) && (p.C0 == 16 || p.C0 == 4) && p.Cout <= 16,
+  D3F_CHECK((p.patch == 1 || p.patch == 3) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
+                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1)) && p.Cout <= 16,
             "conv: patch params were not planned");
-  if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_patch_kernel<4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }

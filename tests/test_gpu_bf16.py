@@ -30,6 +30,8 @@ CASES = [
     (1, 8, 8, 256, 0, 256, 3, 1, 1, False),
     (2, 16, 16, 64, 0, 128, 3, 2, 1, False),
     (2, 16, 16, 64, 0, 128, 1, 2, 0, False),
+    (2, 8, 64, 16, 0, 16, 3, 1, 1, False),        # conv_patch_kernel<bf16, 16, 16> (4 x 64 tiles, 16x16x16 bf16 MFMA)
+    (1, 12, 128, 16, 0, 8, 3, 1, 1, False),       # ... two tiles per row, fewer filters than the tile
     (1, 32, 32, 128, 64, 64, 3, 1, 1, True),      # class-form weight gradient (WG_CLASS + WG_SKIP), bf16 MFMA
     (3, 12, 20, 128, 64, 128, 3, 1, 1, True),     # ... ragged class grid
 ]
