@@ -93,6 +93,9 @@ template <> struct Mma<bf16_t, 16> {
 // is accumulated in fp32 by six bf16 MFMAs (the three dropped terms are <= 2^-24 |a*b|, below the fp32
 // rounding of the accumulation itself; measured error vs float64 equals v_mfma_f32's,
 // profiles/microbench/split_bench.hip).  Six bf16 MFMAs take 6/16 of the time of the fp32 MFMAs they replace.
+#ifndef D3F_FRAG_PREFETCH
+#define D3F_FRAG_PREFETCH 1  // k-chunks the fragment reads run ahead of their MFMAs (0: reads right in front, the A/B variant)
+#endif
 #ifndef D3F_X3_ABLATE
 #define D3F_X3_ABLATE 0  // timing-only ablations (wrong results): 1 no split VALU, 2 one MFMA of six, 3 one plane of fragment reads
 #endif
@@ -635,22 +638,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       }
     } else {
     const uint32_t* Bs = As + BM * LDS_ROW;
-#pragma unroll
-    for (int ss = 0; ss < NS / WGK; ++ss) {
+    constexpr int NSS = NS / WGK;
+    // Fragment reads run PD k-chunks ahead of the MFMAs that consume them: issued right in front of a chunk's MFMAs, a
+    // ds_read_b128's latency (~130 cycles) is covered by one 64-cycle MFMA at best -- four exposed waits per k-tile
+    // (r03: -0.75 % per fp32 step).  The scheduler sinks such reads back to their first use unless it is stopped.
+    constexpr int PD = D3F_FRAG_PREFETCH;
+    uint4 a[NSS][FM], b[NSS][FN];
+    auto read_frags = [&](auto ssc) {
+      constexpr int ss = decltype(ssc)::value;
       const int s = ss * WGK + wk;
       const int ch = (MT == 32) ? (2 * s + fq) : (4 * s + fq);
-      uint4 a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        a[i] = *reinterpret_cast<const uint4*>(&As[(wm * TM + i * MT + fr) * LDS_ROW + ch * 4]);
+        a[ss][i] = *reinterpret_cast<const uint4*>(&As[(wm * TM + i * MT + fr) * LDS_ROW + ch * 4]);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        b[j] = *reinterpret_cast<const uint4*>(&Bs[(wn * TN + j * MT + fr) * LDS_ROW + ch * 4]);
+        b[ss][j] = *reinterpret_cast<const uint4*>(&Bs[(wn * TN + j * MT + fr) * LDS_ROW + ch * 4]);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ((S < PD ? (read_frags(std::integral_constant<int, S>{}), 0) : 0), ...);
+    }(std::make_integer_sequence<int, NSS>{});
+    if constexpr (PD > 0) __builtin_amdgcn_sched_barrier(0);
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      (([&]() {
+         if constexpr (PD == 0) {
+           read_frags(std::integral_constant<int, S>{});
+         } else if constexpr (S + PD < NSS) {
+           read_frags(std::integral_constant<int, S + PD>{});
+           __builtin_amdgcn_sched_barrier(0);
+         }
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+         for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) M_::run(acc[i][j], a[i], b[j], [&]() { hook(n++); });
-    }
+           for (int j = 0; j < FN; ++j) M_::run(acc[i][j], a[S][i], b[S][j], [&]() { hook(n++); });
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, NSS>{});
     }
   };
   auto no_hook = [](int) {};

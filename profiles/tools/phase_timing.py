@@ -13,7 +13,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from denoising_diffusion_deep_fake_amd import _lib, ops
 
-B, S = 16, 256
+B, S = 16, int(os.environ.get("SIZE", 256))
+DTN = os.environ.get("DT", "f32")   # f32 | bf16
+DT = {"f32": ops.F32, "bf16": ops.BF16}[DTN]
+TDT = torch.bfloat16 if DTN == "bf16" else torch.float32
 shapes = {
     "l1 64->64 @/4":      (S // 4, S // 4, 64, 0, 64, 3, 1, 1, False),
     "l2 128->128 @/8":    (S // 8, S // 8, 128, 0, 128, 3, 1, 1, False),
@@ -31,19 +34,19 @@ print(f"{'layer':20s} {'kernel us':>9s} {'wg':>6s} | per workgroup (us): prologu
 for name, (H, W, C0, C1, Co, k, st, pd, up) in shapes.items():
     d = ops.make_desc(B, H, W, C0, C1, Co, k, st, pd, up)
     h0, w0 = (H // 2, W // 2) if up else (H, W)
-    s0 = torch.randn(B, h0, w0, C0, device="cuda")
-    s1 = torch.randn(B, H, W, C1, device="cuda") if C1 else None
+    s0 = torch.randn(B, h0, w0, C0, device="cuda").to(TDT)
+    s1 = torch.randn(B, H, W, C1, device="cuda").to(TDT) if C1 else None
     w = torch.randn(Co, C0 + C1, k, k, device="cuda") * 0.05
-    wf, wd = ops.pack_weights(d, w)
+    wf, wd = ops.pack_weights(d, w, DT)
     for _ in range(3):
-        ops.conv_forward(d, s0, s1, wf, splitk=False)
+        ops.conv_forward(d, s0, s1, wf, DT, splitk=False)
     torch.cuda.synchronize()
     L.d3f_debug_phase_read(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
     e0.record()
     for _ in range(n):
-        ops.conv_forward(d, s0, s1, wf, splitk=False)
+        ops.conv_forward(d, s0, s1, wf, DT, splitk=False)
     e1.record()
     torch.cuda.synchronize()
     L.d3f_debug_phase_read(buf, 1)
