@@ -112,6 +112,19 @@ template <> struct Elem<bf16_t> {
   static constexpr int BKE = 64;
 };
 
+// division by a run-time constant as multiply-high + shift (exact for dividends < 2^31): mul == 0 encodes divisor 1
+static inline void fast_div_setup(unsigned d, unsigned* mul, unsigned* shr) {
+  if (d <= 1) { *mul = 0; *shr = 0; return; }
+  unsigned lg = 0;
+  while ((1ull << lg) < d) ++lg;  // ceil(log2 d)
+  const unsigned p = 31 + lg;
+  *mul = (unsigned)(((1ull << p) + d - 1) / d);
+  *shr = p - 32;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -178,6 +191,9 @@ struct ConvParams {
   const float* bn_coef;
   float* bn_partial;
   const void* bn_a;    // that layer's activation when its ReLU mask cannot be recomputed from y (residual add) or null
+  // m -> (image, row, column) without integer divisions (filled by plan): q = umulhi(n, mul) >> shr for n < 2^31,
+  // mul == 0 stands for a divisor of 1
+  unsigned div_howo_mul, div_howo_shr, div_wo_mul, div_wo_shr;
   int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
 };
 

@@ -217,8 +217,8 @@ __device__ __forceinline__ void par_class(int par, int z, int& py, int& px) {
 }
 __device__ __forceinline__ long par_out_row(const ConvParams& p, int py, int px, int m) {
   const int HoWo = p.Ho * p.Wo;
-  const int b = m / HoWo, r = m - b * HoWo;
-  const int j = r / p.Wo, i = r - j * p.Wo;
+  const int b = fast_div(m, p.div_howo_mul, p.div_howo_shr), r = m - b * HoWo;
+  const int j = fast_div(r, p.div_wo_mul, p.div_wo_shr), i = r - j * p.Wo;
   return ((long)b * (2 * p.Ho) + 2 * j + py) * (2 * p.Wo) + 2 * i + px;
 }
 
@@ -322,9 +322,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < NVA; ++i) {
       const int m = m0 + rbase + 32 * i;
       if (m < p.M) {
-        const int b = m / HoWo;
+        const int b = fast_div(m, p.div_howo_mul, p.div_howo_shr);
         const int r = m - b * HoWo;
-        const int oy = r / p.Wo;
+        const int oy = fast_div(r, p.div_wo_mul, p.div_wo_shr);
         const int ox = r - oy * p.Wo;
         bidx[i] = b;
         iy0[i] = oy * p.stride - p.pad;
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < NVA; ++i) {
       const int m = m0 + rbase + 32 * i;
       const bool rowok = m < p.M;
-      const int b = m / HoWo, r = m - b * HoWo;
-      const int j = r / p.Wo, ii = r - j * p.Wo;
+      const int b = fast_div(m, p.div_howo_mul, p.div_howo_shr), r = m - b * HoWo;
+      const int j = fast_div(r, p.div_wo_mul, p.div_wo_shr), ii = r - j * p.Wo;
       const int ya = j + par_py - 1, xa = ii + par_px - 1;          // low-resolution origin (tap a = b = 0)
       const int yb = 2 * j + par_py - 1, xb = 2 * ii + par_px - 1;  // full-resolution origin of the skip taps
       rowoff[i] = (unsigned)(((b * p.H0s + ya) * p.W0s + xa) * p.C0 + chunk * VE) * (unsigned)sizeof(T);
@@ -395,12 +395,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   // split-K: grid.y cuts the k-tile range; each slice writes raw accumulators to its slab
   // (wave-uniform values that come out of integer divisions live in vector registers unless told otherwise, and
   // everything derived from them -- the whole tap walk of the main loop -- then runs on the vector ALU next to the MFMAs)
-  const int kt_begin = __builtin_amdgcn_readfirstlane((int)((long)nk_total * by / p.splitk));
-  const int kt_end = __builtin_amdgcn_readfirstlane((int)((long)nk_total * (by + 1) / p.splitk));
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.splitk > 1) {  // (nk_total * splitk < 2^31: 32-bit divisions, and none at all for the unsplit launches)
+    kt_begin = (int)((unsigned)nk_total * by / (unsigned)p.splitk);
+    kt_end = (int)((unsigned)nk_total * (by + 1) / (unsigned)p.splitk);
+  }
+  kt_begin = __builtin_amdgcn_readfirstlane(kt_begin);
+  kt_end = __builtin_amdgcn_readfirstlane(kt_end);
   // running (tap, channel) position of the k-tile (regular mode: wave-uniform)
   int t_kh = 0, t_kw = 0, t_c = 0, t_seg = 0;
   if (FAST == 2) {
-    if (kt_begin < nkA) {
+    if (kt_begin == 0) {  // (unsplit launches: no division)
+    } else if (kt_begin < nkA) {
       const int tap = kt_begin / cptA;
       t_c = (kt_begin - tap * cptA) * BKE;
       t_kh = tap >> 1;
@@ -725,8 +731,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       ld_kwleft = 3 - kw0;
     } else {
       const int wp = FAST == 2 ? p.W0s : p.Wv;
-      const int tap0 = kt_begin / cpt, c0 = kt_begin - tap0 * cpt;
-      const int kh0 = tap0 / kw_cur, kw0 = tap0 - kh0 * kw_cur;
+      int tap0 = 0, c0 = 0, kh0 = 0, kw0 = 0;
+      if (kt_begin > 0) {  // (wave-uniform; the unsplit launches skip the divisions)
+        tap0 = kt_begin / cpt;
+        c0 = kt_begin - tap0 * cpt;
+        kh0 = tap0 / kw_cur;
+        kw0 = tap0 - kh0 * kw_cur;
+      }
       ld_delta = (unsigned)((kh0 * wp + kw0) * p.C0 + c0 * BKE) * (unsigned)sizeof(T);
       ld_bit = (unsigned)tap0;
       ld_cleft = cpt - c0;
@@ -963,7 +974,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int r = 0; r < M_::NREG; ++r) {
           const int m = m0 + wm * TM + i * MT + m_local(r);
           if (m >= p.M) continue;
-          const int b = m / HoWo;
+          const int b = fast_div(m, p.div_howo_mul, p.div_howo_shr);
           const int pix = m - b * HoWo;
           out[((long)b * p.Cout + n) * HoWo + pix] = acc[i][j][r] + bias;
         }
@@ -1492,6 +1503,8 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
     D3F_CHECK(p.Kpad == p.KH * p.KW * (p.C0 + p.C1), "conv: regular mode needs Kpad == K");
   }
   p.w_ld = p.Kpad;
+  fast_div_setup((unsigned)(p.Ho * p.Wo), &p.div_howo_mul, &p.div_howo_shr);
+  fast_div_setup((unsigned)p.Wo, &p.div_wo_mul, &p.div_wo_shr);
   D3F_CHECK(p.shift0 == 0 || p.shift0 == 1, "conv: shift0");
   D3F_CHECK(!p.zi || p.shift0 == 1, "conv: zero insertion needs shift0");
   D3F_CHECK(p.par == 3 || (p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0)), "conv: src0 extent");
@@ -1592,6 +1605,13 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
 #endif
   D3F_CHECK(q.nz >= 1 && (q.splitk == 1 || q.stat_rows == cdiv((long)q.nz * q.M, SK_ROWS)),
             "conv: split-K params were not planned");
+  {
+    unsigned m0, s0, m1, s1;
+    fast_div_setup((unsigned)(q.Ho * q.Wo), &m0, &s0);
+    fast_div_setup((unsigned)q.Wo, &m1, &s1);
+    D3F_CHECK(m0 == q.div_howo_mul && s0 == q.div_howo_shr && m1 == q.div_wo_mul && s1 == q.div_wo_shr,
+              "conv: output extent changed after the plan (%d x %d)", q.Ho, q.Wo);
+  }
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);
   if (prof) prof_begin(prof_cls, q.flops, stream);
