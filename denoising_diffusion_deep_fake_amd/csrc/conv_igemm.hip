@@ -373,12 +373,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const bool rowok = iy0[i] > -(1 << 23);
       rowoff[i] = (unsigned)(((bidx[i] * p.Hv + iy0[i]) * p.Wv + ix0[i]) * p.C0 + chunk * VE) * (unsigned)sizeof(T);
       unsigned mk = 0;
-      for (int kh = 0; kh < KH_; ++kh)
-        for (int kw = 0; kw < KW_; ++kw) {
-          const int iy = iy0[i] + kh, ix = ix0[i] + kw;
-          const unsigned ok = (unsigned)(rowok & ((unsigned)iy < (unsigned)p.Hv) & ((unsigned)ix < (unsigned)p.Wv));
-          mk |= ok << (kh * KW_ + kw);
+      if (KH_ <= 4 && KW_ <= 4) {  // (wave-uniform) every filter of the network: column bits once, shifted in per filter row
+        unsigned cols = 0;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+          cols |= (unsigned)((kw < KW_) & ((unsigned)(ix0[i] + kw) < (unsigned)p.Wv)) << kw;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+          const bool ok = rowok & (kh < KH_) & ((unsigned)(iy0[i] + kh) < (unsigned)p.Hv);
+          mk |= ok ? cols << ((kh * KW_) & 31) : 0u;
         }
+      } else {
+        for (int kh = 0; kh < KH_; ++kh)
+          for (int kw = 0; kw < KW_; ++kw) {
+            const int iy = iy0[i] + kh, ix = ix0[i] + kw;
+            const unsigned ok = (unsigned)(rowok & ((unsigned)iy < (unsigned)p.Hv) & ((unsigned)ix < (unsigned)p.Wv));
+            mk |= ok << (kh * KW_ + kw);
+          }
+      }
       vmask[i] = mk;
     }
   }
