@@ -478,56 +478,65 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// grid = (blocks over one input row's W * C/N vectors, B * H rows): the row (b, iy) -- and with it which filter rows
+// reach it -- is block-uniform, the column decode is one multiply-high; the argmax bytes of a vector are one load.
+// (r03: the first form decoded a flat index with four 64-bit divisions and walked all 9 taps under branches: ~600
+// vector instructions per 16 bytes written -- the pass was ALU-bound at 2.6 TB/s.)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout,
                                                           const uint8_t* __restrict__ idx,
                                                           T* __restrict__ din, int accumulate, int B,
-                                                          int H, int W, int C) {
+                                                          int H, int W, int C, unsigned vc_mul, unsigned vc_shr) {
   chain_priority();
   constexpr int N = V16<T>::N;
   const int Ho = H / 2, Wo = W / 2, VC = C / N;
-  const long total = (long)B * H * W * VC;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cv = (int)(i % VC);
-    long t = i / VC;
-    const int ix = (int)(t % W);
-    t /= W;
-    const int iy = (int)(t % H);
-    const int b = (int)(t / H);
-    float g[N];
+  const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;  // (ix, cv) in the row
+  if (j >= W * VC) return;
+  const int ix = fast_div(j, vc_mul, vc_shr), cv = j - ix * VC;
+  const int row = (int)blockIdx.y;  // b * H + iy
+  const int iy = row % H, b = row / H;  // (scalar: block-uniform)
+  // windows containing (iy, ix): window oy covers rows 2*oy-1 .. 2*oy+1 -> an odd row lies in two windows (as their
+  // filter row 0 / 2), an even row in one (filter row 1); the same for columns
+  const int noy = (iy & 1) ? 2 : 1, nox = (ix & 1) ? 2 : 1;
+  const int oy0 = (iy + 1) >> 1, kh0 = (iy & 1) ? 0 : 1;  // second candidate: oy0 - 1 with filter row 2
+  const int ox0 = (ix + 1) >> 1, kw0 = (ix & 1) ? 0 : 1;
+  float g[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) g[k] = 0.f;
-    // windows containing (iy, ix): kh = iy - (2*oy - 1) in {0,1,2}
+  for (int k = 0; k < N; ++k) g[k] = 0.f;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ty = iy + 1 - kh;
-      if (ty < 0 || (ty & 1)) continue;
-      const int oy = ty >> 1;
-      if (oy >= Ho) continue;
+  for (int a = 0; a < 2; ++a) {
+    const int oy = oy0 - a, kh = a ? 2 : kh0;
+    if (a >= noy || oy >= Ho) continue;  // (block-uniform)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tx = ix + 1 - kw;
-        if (tx < 0 || (tx & 1)) continue;
-        const int ox = tx >> 1;
-        if (ox >= Wo) continue;
+    for (int c = 0; c < 2; ++c) {
+      const int ox = ox0 - c, kw = c ? 2 : kw0;
+      if (c < nox && ox < Wo) {
         const long o = (((long)b * Ho + oy) * Wo + ox) * C + cv * N;
         float d[N];
         V16<T>::load(dout + o, d);
-        const int tap = kh * 3 + kw;
+        const unsigned tap = (unsigned)(kh * 3 + kw);
+        uint32_t w[N / 4];
+        if constexpr (N == 4) {
+          w[0] = *reinterpret_cast<const uint32_t*>(idx + o);
+        } else {
+          const uint2 t = *reinterpret_cast<const uint2*>(idx + o);
+          w[0] = t.x;
+          w[1] = t.y;
+        }
 #pragma unroll
         for (int k = 0; k < N; ++k)
-          if (idx[o + k] == tap) g[k] += d[k];
+          if (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == tap) g[k] += d[k];
       }
     }
-    T* dst = din + i * N;
-    if (accumulate) {
-      float old[N];
-      V16<T>::load(dst, old);
-#pragma unroll
-      for (int k = 0; k < N; ++k) g[k] += old[k];
-    }
-    V16<T>::store(dst, g);
   }
+  T* dst = din + ((long)row * W * VC + j) * N;
+  if (accumulate) {
+    float old[N];
+    V16<T>::load(dst, old);
+#pragma unroll
+    for (int k = 0; k < N; ++k) g[k] += old[k];
+  }
+  V16<T>::store(dst, g);
 }
 
 int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
@@ -552,12 +561,17 @@ int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, voi
   D3F_CHECK(C % ve == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: shape (%d,%d,%d)", H, W, C);
   const long total = (long)B * H * W * (C / ve);
   if (total == 0) return 0;
+  const int vc = C / ve;
+  unsigned vc_mul, vc_shr;
+  fast_div_setup((unsigned)vc, &vc_mul, &vc_shr);
+  D3F_CHECK((long)B * H <= 65535, "maxpool backward: %d rows exceed the grid", B * H);
+  const dim3 grid((unsigned)cdiv((long)W * vc, 256), (unsigned)(B * H));
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const float*)dout, idx, (float*)din, accumulate, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, stream,
+                       (const float*)dout, idx, (float*)din, accumulate, B, H, W, C, vc_mul, vc_shr);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream,
+                       (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, B, H, W, C, vc_mul, vc_shr);
   D3F_HIP(hipGetLastError());
   return 0;
 }
