@@ -631,6 +631,13 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       const int crows = std::max(u.Cin(), u.need_dgrad ? u.CinRows : 0);
       const int nrows = std::max(u.CoutPad, u.need_dgrad ? CoutD : 0);
       e.CT = (uint16_t)CT;
+      {
+        unsigned mul, shr;
+        fast_div_setup((unsigned)taps, &mul, &shr);
+        e.taps_mul = mul;
+        e.taps_shr = (uint16_t)shr;
+        e.ct_log2 = (uint16_t)__builtin_ctz((unsigned)CT);
+      }
       e.ctiles = (uint16_t)((crows + CT - 1) / CT);
       blocks += (uint32_t)e.ctiles * (uint32_t)((nrows + PACK_NT - 1) / PACK_NT);
     }

@@ -881,24 +881,28 @@ __device__ __forceinline__ unsigned up_fwd_set(int parity, int a) {  // bitmask 
 }
 __device__ __forceinline__ unsigned up_bwd_set(int u) { return u == 0 ? 4u : u == 1 ? 6u : u == 2 ? 3u : 1u; }
 
+// (the element decode divides by seven run-time constants: multiply-high pairs from the host, fast_div in common.h)
+struct UpDiv {
+  unsigned fplane[2], kc[2], c0[2], c1[2], k9[2], cd[2], k4[2];
+};
 template <typename T, bool X3>
 __global__ __launch_bounds__(256) void pack_up_kernel(const float* __restrict__ w, int Cout, int C0, int C1,
                                                       T* __restrict__ wfc, int CoutPad, T* __restrict__ wd4,
                                                       int C0Rows, T* __restrict__ wds, int C1Rows, int CoutD,
-                                                      int K9) {  // K9: wds row length, 9*CoutD padded to whole k-tiles
+                                                      int K9, UpDiv dv) {  // K9: wds row length, 9*CoutD padded to whole k-tiles
   const int Cin = C0 + C1;
   const int Kc = 4 * C0 + 9 * C1, K4 = 16 * CoutD;
-  const long nf = 4L * CoutPad * Kc, nd = (long)C0Rows * K4, ns = (long)C1Rows * K9;
-  const long fplane = (long)CoutPad * Kc;  // x3: planes of one class
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nf + nd + ns; i += (long)gridDim.x * 256) {
+  const int nf = 4 * CoutPad * Kc, nd = C0Rows * K4, ns = C1Rows * K9;  // (< 2^31 in all: pack_up_launch)
+  const int fplane = CoutPad * Kc;  // x3: planes of one class
+  for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < nf + nd + ns; i += (int)gridDim.x * 256) {
     if (i < nf) {
-      const int z = (int)(i / fplane);
-      const long r = i - (long)z * fplane;
-      const int n = (int)(r / Kc), k = (int)(r % Kc);
+      const int z = fast_div(i, dv.fplane[0], dv.fplane[1]);
+      const int r = i - z * fplane;
+      const int n = fast_div(r, dv.kc[0], dv.kc[1]), k = r - n * Kc;
       float v = 0.f;
       if (n < Cout) {
         if (k < 4 * C0) {
-          const int ab = k / C0, c = k - ab * C0;
+          const int ab = fast_div(k, dv.c0[0], dv.c0[1]), c = k - ab * C0;
           const unsigned sh = up_fwd_set(z >> 1, ab >> 1), sw = up_fwd_set(z & 1, ab & 1);
           const float* __restrict__ wp = w + ((long)n * Cin + c) * 9;
 #pragma unroll
@@ -907,23 +911,23 @@ __global__ __launch_bounds__(256) void pack_up_kernel(const float* __restrict__ 
             for (int kw = 0; kw < 3; ++kw)
               if (((sh >> kh) & 1u) && ((sw >> kw) & 1u)) v += wp[kh * 3 + kw];
         } else {
-          const int kk = k - 4 * C0, tap = kk / C1, c1 = kk - tap * C1;
+          const int kk = k - 4 * C0, tap = fast_div(kk, dv.c1[0], dv.c1[1]), c1 = kk - tap * C1;
           v = w[((long)n * Cin + C0 + c1) * 9 + tap];
         }
       }
       // class blocks are [z][plane][CoutPad][Kc] in x3 mode, [z][CoutPad][Kc] otherwise
       pack_store<T, X3>(wfc + (X3 ? 3L * z * fplane : (long)z * fplane), r, fplane, v);
     } else if (i >= nf + nd) {
-      const long j = i - nf - nd;
-      const int c1 = (int)(j / K9), k = (int)(j % K9);
-      const int f = k / CoutD, n = k - f * CoutD;
+      const int j = i - nf - nd;
+      const int c1 = fast_div(j, dv.k9[0], dv.k9[1]), k = j - c1 * K9;
+      const int f = fast_div(k, dv.cd[0], dv.cd[1]), n = k - f * CoutD;
       float v = 0.f;
       if (c1 < C1 && n < Cout && f < 9) v = w[((long)n * Cin + C0 + c1) * 9 + (8 - f)];
       pack_store<T, X3>(wds, j, ns, v);
     } else {
-      const long j = i - nf;
-      const int c = (int)(j / K4), k = (int)(j % K4);
-      const int uv = k / CoutD, n = k - uv * CoutD;
+      const int j = i - nf;
+      const int c = fast_div(j, dv.k4[0], dv.k4[1]), k = j - c * K4;
+      const int uv = fast_div(k, dv.cd[0], dv.cd[1]), n = k - uv * CoutD;
       float v = 0.f;
       if (c < C0 && n < Cout) {
         const unsigned sh = up_bwd_set(uv >> 2), sw = up_bwd_set(uv & 3);
@@ -948,15 +952,25 @@ int pack_up_launch(int dtype, const float* w, int Cout, int C0, int C1, void* wf
   const int K9 = (int)round_up(9L * CoutD, dtype == D3F_BF16 ? 64 : 32);  // = the data gradient's KpadD
   const long total = 4L * CoutPad * (4 * C0 + 9 * C1) + (long)C0Rows * 16 * CoutD + (long)C1Rows * K9;
   if (total == 0) return 0;
+  D3F_CHECK(total < (1L << 31) - 2048L * 256, "pack_up: %ld elements exceed the 32-bit element index", total);
+  UpDiv dv;
+  auto setup = [](long d, unsigned (&o)[2]) { fast_div_setup((unsigned)(d > 0 ? d : 1), &o[0], &o[1]); };
+  setup((long)CoutPad * (4 * C0 + 9 * C1), dv.fplane);
+  setup(4 * C0 + 9 * C1, dv.kc);
+  setup(C0, dv.c0);
+  setup(C1, dv.c1);
+  setup(K9, dv.k9);
+  setup(CoutD, dv.cd);
+  setup(16 * CoutD, dv.k4);
   if (dtype == D3F_F32)
     hipLaunchKernelGGL((pack_up_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
-                       (float*)wfc, CoutPad, (float*)wd4, C0Rows, (float*)wds, C1Rows, CoutD, K9);
+                       (float*)wfc, CoutPad, (float*)wd4, C0Rows, (float*)wds, C1Rows, CoutD, K9, dv);
   else if (dtype == D3F_F32X3)
     hipLaunchKernelGGL((pack_up_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
-                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9);
+                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9, dv);
   else
     hipLaunchKernelGGL((pack_up_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(256), 0, stream, w, Cout, C0, C1,
-                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9);
+                       (bf16_t*)wfc, CoutPad, (bf16_t*)wd4, C0Rows, (bf16_t*)wds, C1Rows, CoutD, K9, dv);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -979,25 +993,30 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   const int taps = e.taps, Cin = e.Cin, CinReal = e.CinReal, Cout = e.Cout, Kpad = e.Kpad, KpadD = e.KpadD,
             CoutD = e.CoutD, CT = e.CT, CoutPad = e.CoutPad, CinRows = e.CinRows;
   const int rel = (int)(blockIdx.x - e.block0);
-  const int nt = rel / e.ctiles, ct = rel % e.ctiles;
+  const int nt = rel / e.ctiles, ct = rel % e.ctiles;  // (block-uniform)
   const int n0 = nt * PACK_NT, c0 = ct * CT;
   const int run = CT * taps, stride = run + 1;  // LDS row: [c_l][tap]
+  // per-element index arithmetic: CT and the filter tile are powers of two, the only real division is by the tap count
+  // (multiply-high, PackEntry) -- with five integer divisions per element and phase the pass was ALU-bound (r03: 193 us
+  // alone for 265 MB)
+  const unsigned tmul = e.taps_mul, tshr = e.taps_shr, lgct = e.ct_log2;
   // ---- load: contiguous runs of the torch layout, zero outside the real filter ----
   for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
-    const int nl = i / run, r = i % run;
-    const int n = n0 + nl, c = c0 + r / taps;
+    const int nl = fast_div(i >> lgct, tmul, tshr), r = i - nl * run;
+    const int n = n0 + nl, c = c0 + fast_div(r, tmul, tshr);
     float v = 0.f;
-    if (n < Cout && c < CinReal) v = w[((long)n * CinReal + c0) * taps + r];
+    if (n < Cout && c < CinReal) v = w[(unsigned)((n * CinReal + c0) * taps + r)];
     tile[nl * stride + r] = v;
   }
   __syncthreads();
   // ---- forward layout wf[n][tap*Cin + c] ----
   if (e.which & 1)
   for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
-    const int cl = i % CT, tap = (i / CT) % taps, nl = i / run;
+    const int cl = i & (CT - 1), q = i >> lgct;
+    const int nl = fast_div(q, tmul, tshr), tap = q - nl * taps;
     const int n = n0 + nl, c = c0 + cl;
     if (n < CoutPad && c < Cin)
-      pack_store<T, X3>(wf, (long)n * Kpad + tap * Cin + c, (long)CoutPad * Kpad, tile[nl * stride + cl * taps + tap]);
+      pack_store<T, X3>(wf, (long)(unsigned)(n * Kpad + tap * Cin + c), (long)CoutPad * Kpad, tile[nl * stride + cl * taps + tap]);
   }
   if (ct == 0 && (e.which & 1)) {  // zero tail of each row: k in [taps*Cin, Kpad)
     const int k0 = taps * Cin, tail = Kpad - k0;
@@ -1009,10 +1028,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
   if (e.has_d && (e.which & 2)) {
     for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
-      const int nl = i % PACK_NT, slot = (i / PACK_NT) % taps, cl = i / (PACK_NT * taps);
+      const int nl = i & (PACK_NT - 1), q = i / PACK_NT;
+      const int cl = fast_div(q, tmul, tshr), slot = q - cl * taps;
       const int n = n0 + nl, c = c0 + cl;
       if (c < CinRows && n < CoutD)
-        pack_store<T, X3>(wd, (long)c * KpadD + slot * CoutD + n, (long)CinRows * KpadD,
+        pack_store<T, X3>(wd, (long)(unsigned)(c * KpadD + slot * CoutD + n), (long)CinRows * KpadD,
                           tile[nl * stride + cl * taps + (taps - 1 - dgrad_tap_slot_to_flipped(slot, taps, e.conv_stride))]);
     }
     if (nt == 0) {
