@@ -17,17 +17,23 @@ namespace d3f {
 // ------------------------------------------------------------------------------------------
 // tiny reduction used for the head's bias gradient: out[c] = sum_{b,hw} x[b][c][hw]
 // ------------------------------------------------------------------------------------------
-constexpr int CS_PARTS = 64;
-__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int B,
-                                                                  int C, long HW,
+// grid = (CS_PP segments of a plane, C, B): a block sums one contiguous stretch of one (image, channel) plane with
+// 16-byte loads; partial[c][b * CS_PP + segment], summed in that order by the final kernel (fixed order: reproducible)
+constexpr int CS_PP = 16;
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int C, long HW,
                                                                   float* __restrict__ partial) {
   __shared__ float red[256];
-  const int c = blockIdx.y, part = blockIdx.x;
-  const long total = (long)B * HW;
+  const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
+  const float* __restrict__ plane = x + ((long)b * C + c) * HW;
+  const long per = (HW + CS_PP - 1) / CS_PP, lo = (long)seg * per, hi = lo + per < HW ? lo + per : HW;
   float s = 0.f;
-  for (long i = (long)part * 256 + threadIdx.x; i < total; i += (long)CS_PARTS * 256) {
-    const long b = i / HW, p = i - b * HW;
-    s += x[(b * C + c) * HW + p];
+  if ((HW & 3) == 0 && (per & 3) == 0) {
+    for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(plane + i);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) s += plane[i];
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -35,22 +41,23 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[c * CS_PARTS + part] = red[0];
+  if (threadIdx.x == 0) partial[((long)c * nb + b) * CS_PP + seg] = red[0];
 }
-__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int C,
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int C, int n,
                                          float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
-  for (int i = 0; i < CS_PARTS; ++i) s += (double)partial[c * CS_PARTS + i];
+  for (int i = 0; i < n; ++i) s += (double)partial[(long)c * n + i];
   out[c] = (float)s;
 }
+size_t channel_sum_partial_floats(int B, int C) { return (size_t)B * C * CS_PP; }
 int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
                             hipStream_t stream) {
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PARTS, C), dim3(256), 0, stream, x, B, C, HW,
-                     partial);
+  D3F_CHECK(B <= 65535 && C <= 65535, "channel sum: grid (%d, %d)", C, B);
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PP, C, B), dim3(256), 0, stream, x, C, HW, partial);
   D3F_HIP(hipGetLastError());
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, partial, C, out);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, partial, C, B * CS_PP, out);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -522,7 +529,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   dz_off = alloc(dz_bytes);
   dfull_off = alloc(dfull_bytes);
   wpart_off = alloc(wpart_bytes);
-  bsum_off = alloc((size_t)classes * CS_PARTS * sizeof(float));
+  bsum_off = alloc(channel_sum_partial_floats(B, classes) * sizeof(float));
   splitk_off = alloc(splitk_bytes);
   splitk_aux_off = alloc(splitk_aux_bytes);
   head_nchw_off = alloc((size_t)B * classes * H * W * sizeof(float));  // predict_u8: head output before K16 post
