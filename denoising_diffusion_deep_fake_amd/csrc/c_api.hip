@@ -441,6 +441,7 @@ static int wgrad_params(int dtype, const d3f_conv_desc* d, WgradParams& w) {
   w.Ho = g.Ho; w.Wo = g.Wo; w.Cout = g.CoutD;
   w.KH = d->KH; w.KW = d->KW; w.stride = d->stride; w.pad = d->pad;
   w.M = d->B * g.Ho * g.Wo;
+  w.cin_real = d->CinReal;
   return wgrad_plan(w, sdt(dtype));
 }
 size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* d) {

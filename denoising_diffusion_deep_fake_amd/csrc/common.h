@@ -237,6 +237,7 @@ struct WgradParams {
   int Ho, Wo, Cout;
   int KH, KW, stride, pad;
   int M;        // B*Ho*Wo
+  int cin_real; // real (unpadded) input channels when the caller knows them, else 0 = every channel counts
   int splits;   // pixel slabs
   int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;

@@ -46,6 +46,11 @@ template <typename T, int MT, int CI_T, int KS, int S, int TW>
 __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int CO_T = MT;
+  // HALFV (the stem in bf16 storage: 3 image channels padded to one 16-byte vector of 8): only the first CI_T = 4
+  // channels of a pixel's vector are staged -- with 8 staged channels the kernel ran 13 column tiles instead of the fp32
+  // stem's 7 and, last on its stream, 150 us of the bf16 step's tail (profiles/r03_end_bf16_step_timeline.txt)
+  constexpr bool HALFV = CI_T < VE;
+  static_assert(!HALFV || (CI_T == 4 && VE == 8), "half vectors: 4 of 8 bf16 channels");
   constexpr int PH = (PT_TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int KSTEP = (MT == 32) ? 2 : 4;            // pixels per MFMA
   constexpr int NCOL = KS * KS * CI_T;                 // (tap, ci) columns
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
   // channels this launch covers: all of them, or one source's (WgradParams::part: WG_SKIP = source 1 only); its slabs
   // are slab_cin wide and hold launch-local channel indices
   const int Cin = p.slab_cin;
-  const int ci_slices = Cin / CI_T;
+  const int ci_slices = HALFV ? 1 : Cin / CI_T;
   const int slice = blockIdx.y;
   const int cil0 = (slice % ci_slices) * CI_T;           // launch-local
   const int ci0 = p.ci_base + cil0, co0 = (slice / ci_slices) * CO_T;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + PT_TH - 1) / PT_TH;
   const int ntiles = p.B * tiles_y * tiles_x;
-  constexpr int VX = CI_T / VE, VY = CO_T / VE;  // 16-byte global vectors per pixel row
+  constexpr int VX = HALFV ? 1 : CI_T / VE, VY = CO_T / VE;  // 16-byte global vectors per pixel row
 
   // staging: every load of a tile is issued into registers first (no load -> wait -> store chains),
   // and the NEXT tile's loads are issued before the MFMA sweep of the current one.
@@ -138,7 +143,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
     for (int i = 0; i < NVX; ++i) {
       const int v = tid + i * 256;
       const int pix = v / VX, cv = v - pix * VX;
-      if (v < PH * PW * VX) patch_store_f32<T>(&Xs[pix * LXS + cv * VE], rxv[i]);
+      if (v < PH * PW * VX) {
+        if constexpr (HALFV)
+          *reinterpret_cast<uint4*>(&Xs[pix * LXS]) =
+              make_uint4(rxv[i].x << 16, rxv[i].x & 0xffff0000u, rxv[i].y << 16, rxv[i].y & 0xffff0000u);
+        else
+          patch_store_f32<T>(&Xs[pix * LXS + cv * VE], rxv[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NVY; ++i) {
@@ -200,7 +211,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
       const int co = co0 + e / MT;
       const int n = j * MT + (e % MT);
       const int tap = n / CI_T, ci = cil0 + (n - tap * CI_T);
-      if (co < p.Cout && tap < taps) slab[((long)co * taps + tap) * Cin + ci] = s;
+      if (co < p.Cout && tap < taps) {
+        slab[((long)co * taps + tap) * Cin + ci] = s;
+        if constexpr (HALFV) slab[((long)co * taps + tap) * Cin + ci + CI_T] = 0.f;  // the unstaged padding channels
+      }
     }
   }
 }
@@ -352,7 +366,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradPa
 
 // variants: 1: 3x3 s1, <=16 out, 32-channel slices (decoder 4 conv1)   2: 3x3 s1, <=16 out, 16-channel slices
 //           3: 3x3 s1, 32-out slices, 32-channel slices (decoder 3)     4: 7x7 s2 stem, 4 (3+pad) channels
-//           5: 7x7 s2 stem in bf16 storage, 8 (3+pad) channels (the tap-parallel kernel took 725 us for this
+//           6: as 5 with at most 4 real channels: 4 of the 8 are staged      5: 7x7 s2 stem in bf16 storage, 8 (3+pad)
+//              channels (the tap-parallel kernel took 725 us for this
 //              layer -- 49 taps x 2 filter tiles re-reading the 128x128 dY 49 times -- and sat at the very end of the
 //              weight-gradient stream: profiles/r03_bf16_step_timeline.txt)
 int wgrad_patch_variant(const WgradParams& p, int dtype) {
@@ -367,15 +382,15 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
       p.Cout % 32 == 0 && p.Cout <= 64)
     return 4;  // f32: 3 channels padded to 4
   if (dtype == D3F_BF16 && p.KH == 7 && p.stride == 2 && p.pad == 3 && cin == 8 && p.C1 == 0 &&
-      p.Cout % 32 == 0 && p.Cout <= 64)
-    return 5;  // bf16 pads the stem input to 8 channels (one 16-byte vector per pixel)
+      p.Cout % 32 == 0 && p.Cout <= 64)  // bf16 pads the stem input to 8 channels (one 16-byte vector per pixel)
+    return (p.cin_real > 0 && p.cin_real <= 4) ? 6 : 5;  // 6: only the first 4 are staged (RGB: 3 real channels)
   return 0;
 }
 
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   const int cin = p.part == WG_WHOLE ? p.C0 + p.C1 : p.part == WG_CLASS ? p.C0 : p.C1;  // channels of this launch
-  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : variant == 5 ? 8 : 4;
-  const int co_t = (variant == 3 || variant == 4 || variant == 5) ? 32 : 16;
+  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : (variant == 5 || variant == 6) ? 8 : 4;
+  const int co_t = (variant == 3 || variant == 4 || variant == 5 || variant == 6) ? 32 : 16;
   const int slices = (cin / ci_t) * cdiv(p.Cout, co_t) * (p.part == WG_CLASS ? 2 : 1);  // class form: x 2 row parities
   const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
   int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
@@ -420,6 +435,9 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
   } else if (variant == 5) {
     D3F_CHECK(dtype == D3F_BF16, "wgrad patch: stem variant 5 is the bf16 one");
     hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 8, 7, 2, 16>), grid, block, 0, stream, p);
+  } else if (variant == 6) {
+    D3F_CHECK(dtype == D3F_BF16, "wgrad patch: stem variant 6 is a bf16 one");
+    hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (dtype == D3F_F32) {
     if (int rc = patch_launch_t<float>(p, variant, grid, stream)) return rc;
   } else {

@@ -203,6 +203,7 @@ int UnetEngine::plan_unit(Unit& u) {
   g.H0s = u.Hv >> u.up0; g.W0s = u.Wv >> u.up0; g.shift0 = u.up0;
   g.Ho = u.Ho; g.Wo = u.Wo; g.Cout = u.CoutD;
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = (int)rows_full;
+  g.cin_real = u.CinReal;
   g.flops = 2.0 * macs;
   {
     const WgradParams base = g;

@@ -80,6 +80,28 @@ def test_conv_bf16(case):
     assert rel_l2(dw.cpu(), wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 36, 52)], ids=str)
+def test_stem_weight_gradient_bf16_half_vector(shape):
+    """encoder.conv1 (7x7 stride 2) in bf16 storage: 3 image channels padded to one 16-byte vector of 8.  With the real
+    channel count known (<= 4) the patch kernel stages only the first four (variant 6); the gradient must equal the
+    eight-channel kernel's (variant 5) bit for bit and torch's to fp32 accuracy (the operands are exact in bf16)."""
+    from denoising_diffusion_deep_fake_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(B, 64, H // 2, W // 2, generator=g).bfloat16().float()
+    want = torch.nn.grad.conv2d_weight(x, (64, 3, 7, 7), dy, stride=2, padding=3)
+    xh = to_nhwc(x, 8).bfloat16().cuda()
+    dyh = to_nhwc(dy).bfloat16().cuda()
+    d6 = ops.make_desc(B, H, W, 8, 0, 64, 7, 2, 3, False, cin_real=3)
+    d5 = ops.make_desc(B, H, W, 8, 0, 64, 7, 2, 3, False, cin_real=8)
+    g6 = ops.conv_backward_weight(d6, dyh, xh, None, dtype=ops.BF16)
+    g5 = ops.conv_backward_weight(d5, dyh, xh, None, dtype=ops.BF16)
+    assert tuple(g6.shape) == (64, 3, 7, 7) and tuple(g5.shape) == (64, 8, 7, 7)
+    assert torch.equal(g6, g5[:, :3]) and float(g5[:, 3:].abs().max()) == 0.0
+    assert rel_l2(g6.cpu(), want) < 1e-5
+
+
 def test_unet_bf16_training_step():
     import oracle
     from denoising_diffusion_deep_fake_amd import Unet, ops
