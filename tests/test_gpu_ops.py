@@ -204,6 +204,32 @@ def test_maxpool_fwd_bwd(ops):
     torch.testing.assert_close(acc.cpu(), (base + din).cpu())
 
 
+@pytest.mark.parametrize("shape,bf16", [((3, 24, 20, 36), False), ((2, 64, 32, 64), False), ((2, 24, 16, 40), True),
+                                        ((1, 64, 8, 96), True)], ids=str)
+def test_maxpool_backward_shapes(ops, shape, bf16):
+    """channel counts that are no power of two (the column decode divides by C / 4 or C / 8 through a multiply-high),
+    rows wider than one workgroup, both storage types, with and without accumulation into an existing gradient"""
+    B, C, H, W = shape
+    dt = ops.BF16 if bf16 else ops.F32
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(11)
+    x = F.relu(torch.randn(B, C, H, W, generator=g))
+    dy = torch.randn(B, C, H // 2, W // 2, generator=g)
+    if bf16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    y_ref.backward(dy)
+    out, idx = ops.maxpool_forward(to_nhwc(x).to(tdt).cuda(), dtype=dt)
+    assert torch.equal(to_nchw(out.float().cpu()), y_ref.detach())
+    din = ops.maxpool_backward(to_nhwc(dy).to(tdt).cuda(), idx, H, W, dtype=dt)
+    tol = dict(rtol=1e-2, atol=1e-2) if bf16 else dict(rtol=1e-6, atol=1e-6)  # bf16: the sum of up to 4 windows is rounded
+    torch.testing.assert_close(to_nchw(din.float().cpu()), xr.grad, **tol)
+    base = torch.full_like(din, 0.5)
+    acc = ops.maxpool_backward(to_nhwc(dy).to(tdt).cuda(), idx, H, W, dtype=dt, din=base.clone())
+    torch.testing.assert_close(acc.float().cpu(), (din.float() + 0.5).cpu(), **tol)
+
+
 def test_noise_blend_matches_golden(ops, golden_dir):
     g = np.load(golden_dir / "blend.npz")
     x = torch.from_numpy(g["x"])
