@@ -272,3 +272,21 @@ def test_console_script_entry_point_resolves():
     assert {"d3f", "denoising_diffusion_deep_fake_amd*"} <= found
     data = meta["tool"]["setuptools"]["package-data"]["denoising_diffusion_deep_fake_amd"]
     assert any(p.endswith("libd3f_hip.so") for p in data) and any(p.endswith(".yml") for p in data)
+
+
+def test_division_by_multiply_high_is_exact(tmp_path):
+    """csrc/common.h: the conv prologue, the max-pool backward and the pack kernels decode indices with
+    q = umulhi(n, mul) >> shr instead of an integer division; the host-made constants must make that exact for every
+    dividend below 2^31 (tests/aux/fast_div_check.hip restates the device formula with a 64-bit product)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "fast_div_check"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20",
+                    "-I", str(root / "denoising_diffusion_deep_fake_amd" / "csrc"),
+                    str(root / "tests" / "aux" / "fast_div_check.hip"), "-o", str(exe)], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout + out.stderr
