@@ -50,6 +50,10 @@ struct Unit {
   // resolution: no full-resolution scratch, no 2x2 sum) and the skip tensor's 3x3 data gradient as its own launch
   bool upfold = false;
   size_t wfc_off = 0, wd4_off = 0, wds_off = 0;
+  // train-mode forward as Winograd F(2x2, 3x3) (conv_winograd.hip): transformed filters, statistics rows
+  bool wino = false;
+  size_t wu_off = 0;
+  int wino_rows = 0;
   int C0Rows = 0, C1Rows = 0;
   ConvParams dgrad_lo{};
   int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)

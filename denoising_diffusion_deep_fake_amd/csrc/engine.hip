@@ -187,8 +187,13 @@ int UnetEngine::plan_unit(Unit& u) {
   f.flops = 2.0 * macs;
   fwd_flops += 2.0 * macs;
   bwd_flops += 2.0 * macs;  // weight gradient
+  u.wino = u.bn && !u.upfold && cdtype == D3F_F32 && conv_winograd_applies(f, cdtype);
+  if (u.wino) {
+    u.wino_rows = conv_winograd_stat_rows(f);
+    u.wu_off = alloc(conv_winograd_filter_floats(f) * sizeof(float));
+  }
   if (u.bn) {
-    const size_t sb = (size_t)f.stat_rows * u.CoutPad * 2 * sizeof(float);
+    const size_t sb = (size_t)std::max(f.stat_rows, u.wino_rows) * u.CoutPad * 2 * sizeof(float);
     if (sb > stats_bytes) stats_bytes = sb;
     const size_t pb = (size_t)bn_bwd_reduce_blocks(rows_full, u.Cout, dtype) * u.Cout * 2 * sizeof(float);
     if (pb > bnpart_bytes) bnpart_bytes = pb;
@@ -660,6 +665,14 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     }
     if (t.n > 0)
       if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
+    if (part < 3)  // transformed filters of the Winograd layers of this part, behind its plain layouts
+      for (int ui = 0; ui < (int)units.size(); ++ui) {
+        const Unit& u = units[ui];
+        if (!u.wino) continue;
+        if (first_late_unit_ > 0 ? part_of(ui) != part : part != 0) continue;
+        if (int rc = conv_winograd_pack_launch(params_ + u.w_off, reinterpret_cast<float*>(ws + u.wu_off), u.Cout, u.Cin(), ps))
+          return rc;
+      }
     if (part == 1 && async) {
       D3F_HIP(hipEventRecord(ev_pack_mid_, side_));
       pack_mid_pending_ = true;
@@ -749,7 +762,13 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       p.out0 = T(u.y);
       p.stats = reinterpret_cast<float*>(ws + stats_off);
       p.partial = p.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
-      if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
+      if (u.wino) {  // Winograd F(2x2, 3x3): its own filter layout and one statistics row per workgroup
+        p.w = ws + u.wu_off;
+        p.stat_rows = u.wino_rows;
+        if (int rc = conv_winograd_launch(p, s)) return rc;
+      } else if (int rc = conv_igemm_launch(p, cdtype, s)) {
+        return rc;
+      }
       const long rows = (long)B * u.Ho * u.Wo;  // (p.M counts one output-parity class for a folded layer)
       const bool sync = bn_sync_fn_ != nullptr;
       if (sync) {  // statistics over every rank's batch: the partial rows are summed across ranks in place
@@ -795,7 +814,12 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
         p.out0 = T(u.y);  // downsample branch: bn(conv(x)) lands in its y slot
         p.res = nullptr;
       }
-      if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
+      if (u.wino) {
+        p.w = ws + u.wu_off;
+        if (int rc = conv_winograd_launch(p, s)) return rc;
+      } else if (int rc = conv_igemm_launch(p, cdtype, s)) {
+        return rc;
+      }
     }
   }
   return 0;
