@@ -223,9 +223,7 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
 bool conv_winograd_applies(const ConvParams& p, int dtype);
 int conv_winograd_stat_rows(const ConvParams& p);           // one statistics row per workgroup
 size_t conv_winograd_filter_floats(const ConvParams& p);    // U[16][Cin / 16][Cout][16]
-// dgrad != 0: the flipped, transposed filters of the data gradient (filters = the layer's input channels)
-int conv_winograd_pack_launch(const float* w /*[Cout][Cin][3][3]*/, float* u, int filters, int channels, int dgrad,
-                              hipStream_t stream);
+int conv_winograd_pack_launch(const float* w /*[Cout][Cin][3][3]*/, float* u, int Cout, int Cin, hipStream_t stream);
 int conv_winograd_launch(const ConvParams& p /*w = U*/, hipStream_t stream);
 bool conv_patch_applies(const ConvParams& p, int dtype);
 bool conv_stem_applies(const ConvParams& p, int dtype);  // encoder.conv1 (7x7 stride 2, 4 staged channels)

@@ -36,10 +36,7 @@ __device__ __forceinline__ int vsw(int row, int ch) { return ch ^ ((row >> 2) & 
 bool conv_winograd_applies(const ConvParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_WINOGRAD") != nullptr;  // debugging knob: the implicit GEMM instead
   if (off || dtype != D3F_F32) return false;
-  // train-mode forward, or the data gradient of such a layer (one destination): the same contraction with the filters
-  // flipped and transposed (conv_winograd_pack_launch)
-  const bool mode_ok = p.mode == CONV_RAW_STATS || (p.mode == CONV_DGRAD && p.out_c0 == p.Cout && p.out1 == nullptr);
-  if (!mode_ok || p.par != 0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 ||
+  if (p.mode != CONV_RAW_STATS || p.par != 0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 ||
       p.shift0 != 0 || p.zi != 0 || p.Ho != p.Hv || p.Wo != p.Wv || (p.Ho % 16) != 0 || (p.Wo % 16) != 0 ||
       (p.C0 % WCK) != 0 || (p.Cout % 64) != 0 || p.CoutPad < p.Cout)
     return false;
@@ -53,18 +50,15 @@ size_t conv_winograd_filter_floats(const ConvParams& p) { return (size_t)16 * p.
 
 // U[pos = 4 i + j][c / 16][k][c % 16] = (G g G^T)[i][j],  g = w[k][c] (torch layout [K][C][3][3]),
 // G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
-// dgrad != 0: the data gradient's filters g'[c][k][a][b] = w[k][c][2 - a][2 - b] -- K counts the layer's INPUT channels
-// (the outputs of the data gradient), C its filters (the channels of dY)
-__global__ __launch_bounds__(256) void winograd_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
-                                                            int dgrad) {
+__global__ __launch_bounds__(256) void winograd_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C) {
   const int id = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (id >= K * C) return;
   const int k = id / C, c = id - k * C;
-  const float* g = dgrad ? w + ((long)c * K + k) * 9 : w + (long)id * 9;
+  const float* g = w + (long)id * 9;
   float t[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float g0 = dgrad ? g[8 - j] : g[j], g1 = dgrad ? g[5 - j] : g[3 + j], g2 = dgrad ? g[2 - j] : g[6 + j];
+    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
     t[0][j] = g0;
     t[1][j] = 0.5f * (g0 + g1 + g2);
     t[2][j] = 0.5f * (g0 - g1 + g2);
@@ -81,9 +75,9 @@ __global__ __launch_bounds__(256) void winograd_pack_kernel(const float* __restr
   }
 }
 
-int conv_winograd_pack_launch(const float* w, float* u, int K, int C, int dgrad, hipStream_t stream) {
+int conv_winograd_pack_launch(const float* w, float* u, int K, int C, hipStream_t stream) {
   D3F_CHECK((C % WCK) == 0 && K > 0 && C > 0, "winograd pack: %d filters x %d channels", K, C);
-  hipLaunchKernelGGL(winograd_pack_kernel, dim3((unsigned)cdiv((long)K * C, 256)), dim3(256), 0, stream, w, u, K, C, dgrad);
+  hipLaunchKernelGGL(winograd_pack_kernel, dim3((unsigned)cdiv((long)K * C, 256)), dim3(256), 0, stream, w, u, K, C);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -253,17 +247,6 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams p) 
     }
     return;
   }
-  // train-mode forward: y + per-channel (sum, sum of squares); data gradient: dX (+= when accumulating) and, fused, the
-  // BatchNorm-backward partial sums of the layer that consumes dX (conv_igemm.hip: g = dX under that layer's ReLU mask,
-  // sums of g and g * xhat)
-  const bool dgrad = p.mode == CONV_DGRAD;
-  const bool fuse = dgrad && p.bn_partial != nullptr;
-  const float* __restrict__ by_ = reinterpret_cast<const float*>(p.bn_y);
-  const float* __restrict__ ba_ = reinterpret_cast<const float*>(p.bn_a);
-  float mu = 0.f, is = 0.f, sc = 0.f, sf = 0.f;
-  if (fuse) {
-    mu = p.bn_coef[n]; is = p.bn_coef[K + n]; sc = p.bn_coef[2 * K + n]; sf = p.bn_coef[3 * K + n];
-  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -275,35 +258,19 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams p) 
       t0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
       t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
     }
-    float o[4] = {t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]};
-    const long base = (((long)b * H + oy) * W + ox) * K + n;
-    const long off[4] = {0, K, (long)W * K, (long)W * K + K};
-    if (!dgrad) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) y[base + off[e]] = o[e];
-      s1 += (o[0] + o[1]) + (o[2] + o[3]);
-      s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = o[e];
-        if (p.acc0) v += y[base + off[e]];
-        y[base + off[e]] = v;
-        if (fuse) {
-          const float yy = by_[base + off[e]];
-          const float keep = ba_ != nullptr ? ba_[base + off[e]] : yy * sc + sf;
-          const float g = keep > 0.f ? v : 0.f;
-          s1 += g;
-          s2 += g * ((yy - mu) * is);
-        }
-      }
-    }
+    const float o00 = t0[0] + t0[1] + t0[2], o01 = t0[1] - t0[2] - t0[3];
+    const float o10 = t1[0] + t1[1] + t1[2], o11 = t1[1] - t1[2] - t1[3];
+    float* o = y + (((long)b * H + oy) * W + ox) * K + n;
+    o[0] = o00;
+    o[K] = o01;
+    o[(long)W * K] = o10;
+    o[(long)W * K + K] = o11;
+    s1 += (o00 + o01) + (o10 + o11);
+    s2 += (o00 * o00 + o01 * o01) + (o10 * o10 + o11 * o11);
   }
-  float* rows = dgrad ? (fuse ? p.bn_partial : nullptr) : p.stats;
-  if (rows != nullptr) {
+  if (p.stats != nullptr) {
     // per-channel sums of the workgroup's 256 pixels: the two k halves of a wave (lanes l, l + 32 hold the same filter),
     // then the two tile halves (waves mt = 0, 1) through LDS, in that order
-    const int ld = dgrad ? K : p.CoutPad;
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     float* red = P;  // [mt][64 filters][2]
@@ -313,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams p) 
     }
     __syncthreads();
     if (tid < 64) {
-      float* st = rows + ((long)blk * ld + n0 + tid) * 2;
+      float* st = p.stats + ((long)blk * p.CoutPad + n0 + tid) * 2;
       st[0] = red[tid * 2 + 0] + red[(64 + tid) * 2 + 0];
       st[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
     }
@@ -322,16 +289,14 @@ __global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams p) 
 
 int conv_winograd_launch(const ConvParams& p, hipStream_t stream) {
   D3F_CHECK(p.src0 && p.w && p.out0 && (p.Hv % 16) == 0 && (p.Wv % 16) == 0 && (p.C0 % WCK) == 0 && (p.Cout % 64) == 0 &&
-                (p.mode == CONV_RAW_STATS || (p.mode == CONV_EVAL_FUSED && p.scale && p.shift) ||
-                 (p.mode == CONV_DGRAD && p.out_c0 == p.Cout && (p.bn_partial == nullptr || (p.bn_y && p.bn_coef)))),
+                (p.mode == CONV_RAW_STATS || (p.mode == CONV_EVAL_FUSED && p.scale && p.shift)),
             "winograd conv: bad description");
   ConvParams q = p;
   q.src0_bytes = (unsigned)((size_t)p.B * p.Hv * p.Wv * p.C0 * 4);
   q.w_bytes = (unsigned)((size_t)16 * p.C0 * p.Cout * 4);
   const dim3 grid((unsigned)(p.B * (p.Hv / 16) * (p.Wv / 16)), (unsigned)(p.Cout / 64));
-  const int cls = p.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
-  const bool prof = prof_enabled(cls);
-  if (prof) prof_begin(cls, q.flops, stream);  // the algorithmic (direct) FLOP count of the layer
+  const bool prof = prof_enabled(PROF_CONV_FWD);
+  if (prof) prof_begin(PROF_CONV_FWD, q.flops, stream);  // the algorithmic (direct) FLOP count of the layer
   hipLaunchKernelGGL(conv_winograd_kernel, grid, dim3(256), 0, stream, q);
   if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());

@@ -54,9 +54,6 @@ struct Unit {
   bool wino = false;
   size_t wu_off = 0;
   int wino_rows = 0;
-  bool wino_d = false;   // ... and its data gradient (flipped, transposed filters; one partial row per workgroup)
-  size_t wud_off = 0;
-  int wino_d_rows = 0;
   int C0Rows = 0, C1Rows = 0;
   ConvParams dgrad_lo{};
   int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)

@@ -286,11 +286,6 @@ int UnetEngine::plan_unit(Unit& u) {
     if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
     d.flops = 2.0 * macs;
     bwd_flops += 2.0 * macs;
-    u.wino_d = cdtype == D3F_F32 && u.CinReal == u.Cin() && u.CoutD == u.Cout && conv_winograd_applies(d, cdtype);
-    if (u.wino_d) {
-      u.wino_d_rows = conv_winograd_stat_rows(d);
-      u.wud_off = alloc(conv_winograd_filter_floats(d) * sizeof(float));
-    }
     if (u.up0) {
       const size_t fb = (size_t)d.M * u.C0 * esize();
       if (fb > dfull_bytes) dfull_bytes = fb;
@@ -480,7 +475,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       D3F_CHECK(pd.Cout == uc.Cout && pd.M == B * uc.Ho * uc.Wo && pd.out_c0 == pd.Cout,
                 "plan: fused BatchNorm reduce shape mismatch (%s -> %s)", up.conv_name.c_str(), uc.conv_name.c_str());
       pj.fuse_for_unit = ck.unit;
-      ck.fused_rows = (!up.upfold && up.wino_d) ? up.wino_d_rows : pd.splitk > 1 ? pd.stat_rows : pd.tiles_m;
+      ck.fused_rows = pd.splitk > 1 ? pd.stat_rows : pd.tiles_m;
       bnpart_bytes = std::max(bnpart_bytes, (size_t)ck.fused_rows * uc.Cout * 2 * sizeof(float));
     }
   }
@@ -675,15 +670,7 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
         const Unit& u = units[ui];
         if (!u.wino) continue;
         if (first_late_unit_ > 0 ? part_of(ui) != part : part != 0) continue;
-        if (int rc = conv_winograd_pack_launch(params_ + u.w_off, reinterpret_cast<float*>(ws + u.wu_off), u.Cout, u.Cin(), 0, ps))
-          return rc;
-      }
-    if (part < 3)
-      for (int ui = 0; ui < (int)units.size(); ++ui) {
-        const Unit& u = units[ui];
-        if (!u.wino_d) continue;
-        if (first_late_unit_ > 0 ? part_of(ui) != part : part != 0) continue;
-        if (int rc = conv_winograd_pack_launch(params_ + u.w_off, reinterpret_cast<float*>(ws + u.wud_off), u.Cin(), u.Cout, 1, ps))
+        if (int rc = conv_winograd_pack_launch(params_ + u.w_off, reinterpret_cast<float*>(ws + u.wu_off), u.Cout, u.Cin(), ps))
           return rc;
       }
     if (part == 1 && async) {
@@ -1291,12 +1278,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         d.bn_partial = reinterpret_cast<float*>(ws + bnpart_off);
         d.bn_a = (uc.res_tensor >= 0 || uc.res_unit >= 0) ? T(uc.a) : nullptr;
       }
-      if (u.wino_d) {  // Winograd F(2x2, 3x3) with the flipped, transposed filters
-        d.w = ws + u.wud_off;
-        if (int rc = conv_winograd_launch(d, s)) return rc;
-      } else if (int rc = conv_igemm_launch(d, cdtype, s)) {
-        return rc;
-      }
+      if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
     }
   }
   if (int rc = flush_pending()) return rc;
