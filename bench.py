@@ -535,7 +535,7 @@ def main():
                    "whole_step_frac_of_peak": round(whole / peak, 4)},
     }
     if use_events and n[0] > 0 and n[1] > 0:
-        names = ["conv_igemm_kernel + conv_patch_kernel (forward launches)",
+        names = ["conv_igemm_kernel + conv_patch_kernel + conv_winograd_kernel (forward launches)",
                  "conv_igemm_kernel + conv_patch_kernel (data-gradient launches)",
                  "conv_wgrad_* (weight-gradient launches)"]
         nsteps = [sampled, sampled, diag]
@@ -559,7 +559,9 @@ def main():
                            # forward launches alone (uncontended): comparable with round 1's forward-only figure
                            "frac_forward": round(fl[0] / max(ms[0], 1e-9) / 1e9 / peak, 4),
                            "kernel": f"conv_igemm_kernel (+ conv_patch_kernel, its LDS-patch form for the 16-channel "
-                                     f"full-resolution layers), ALL launches ({int(n[0]) // sampled} forward + "
+                                     f"full-resolution layers, + conv_winograd_kernel, the F(2x2,3x3) form of the wide "
+                                     f"stride-1 3x3 forward layers; FLOPs counted as the direct convolution's), "
+                                     f"ALL launches ({int(n[0]) // sampled} forward + "
                                      f"{int(n[1]) // sampled} data-gradient per step)",
                            "launches": int(n_all),
                            "sampled_steps": f"{sampled} steps right after the {args.steps} timed steps (HIP events on the "

@@ -21,7 +21,8 @@ def main(out_dir, json_path, head="unknown", date=""):
     n = collections.Counter()
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        cls = ("conv_igemm" if "conv_igemm" in name else "conv_wgrad_patch" if "conv_wgrad_patch" in name
+        cls = ("conv_igemm" if "conv_igemm" in name else "conv_winograd" if "conv_winograd" in name
+               else "conv_wgrad_patch" if "conv_wgrad_patch" in name
                else "conv_wgrad" if "conv_wgrad_kernel" in name else "conv_patch" if "conv_patch_kernel" in name
                else None)
         if cls is None:

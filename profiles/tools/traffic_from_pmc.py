@@ -76,8 +76,11 @@ def main(out_dir, traffic_json, kernels_json, head, date):
     json.dump({"source": src, "git_head": head, "csrc_digest": _digest(), "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
                "kernels": kernels}, open(kernels_json, "w"), indent=1)
     # the roofline kernel family: conv_igemm_kernel and its LDS-patch form for the 16-channel full-resolution layers
-    ci = [a + b for a, b in zip(agg["conv_igemm_kernel"], agg.get("conv_patch_kernel", [0, 0.0, 0.0, 0.0]))]
-    res = {"kernel": "conv_igemm_kernel + conv_patch_kernel (ALL launches: forward + data gradient)", "git_head": head, "csrc_digest": _digest(),
+    zero = [0, 0.0, 0.0, 0.0]
+    ci = [a + b + c for a, b, c in zip(agg["conv_igemm_kernel"], agg.get("conv_patch_kernel", zero),
+                                       agg.get("conv_winograd_kernel", zero))]
+    res = {"kernel": "conv_igemm_kernel + conv_patch_kernel + conv_winograd_kernel (ALL launches: forward + data gradient)",
+           "git_head": head, "csrc_digest": _digest(),
            "date": date,
            "launches_sampled": ci[0], "launches_per_step": round(ci[0] / n, 1),
            "fetch_size_kb_mean": round(ci[1] / ci[0], 1), "write_size_kb_mean": round(ci[2] / ci[0], 1),
