@@ -530,6 +530,8 @@ def main():
                    "ranks_seen": dist.get_world_size() if world > 1 else 1,
                    # every tuning / debugging knob of libd3f_hip.so that was set in the environment of this run
                    "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")},
+                   # digest of the sources baked into the loaded libd3f_hip.so (= the sources next to it unless D3F_LIB)
+                   "csrc_digest": _lib.built_digest(),
                    "conv_gflop_per_image_step": round(step_flops / args.batch / 1e9, 3),
                    "whole_step_conv_tflops": round(whole, 2),
                    "whole_step_frac_of_peak": round(whole / peak, 4)},

@@ -31,6 +31,7 @@ _desc = C.POINTER(ConvDesc)
 PROTOTYPES = {
     "d3f_version": (_i, []),
     "d3f_last_error": (C.c_char_p, []),
+    "d3f_source_digest": (C.c_char_p, []),
     "d3f_profile_enable": (_i, [_i]),
     "d3f_profile_classes": (_i, [_i]),
     "d3f_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -130,8 +131,20 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("D3F_LIB"):
+        built, here = handle.d3f_source_digest().decode(), source_digest()
+        if built != here:
+            raise D3FError(
+                f"{LIB_PATH} was built from other sources (digest {built}) than the ones next to it ({here}): "
+                f"rebuild it with `make -C {LIB_PATH.parent}`, or name a variant build explicitly through D3F_LIB")
     _lib = handle
     return _lib
+
+
+def built_digest():
+    """Digest baked into the loaded library (equals source_digest() unless D3F_LIB names a variant build)."""
+    handle = lib()
+    return handle.d3f_source_digest().decode() if hasattr(handle, "d3f_source_digest") else None
 
 
 def check(rc):
