@@ -314,6 +314,9 @@ int d3f_unet_train_step(d3f_unet_t h, const d3f_step_buffers* b, float lam, floa
   D3F_CHECK(b->params && b->bnstats && b->grads && b->exp_avg && b->exp_avg_sq && b->image && b->noise && b->y_uniform &&
                 b->noisy && b->pred && b->grad_pred && b->loss_out && b->loss_workspace && b->adam_coef,
             "unet_train_step: null buffer");
+  D3F_CHECK(!h->e.bn_sync_installed(),
+            "unet_train_step: synchronised BatchNorm statistics call back into the host inside the pass; the captured "
+            "step is the single-GPU form (use forward / backward)");
   UnetEngine::StepArgs a;
   std::memset(&a, 0, sizeof(a));  // (the struct is compared bytewise as the graph's key)
   a.params = b->params; a.bnstats = b->bnstats; a.grads = b->grads; a.exp_avg = b->exp_avg; a.exp_avg_sq = b->exp_avg_sq;

@@ -40,6 +40,8 @@ bool conv_winograd_applies(const ConvParams& p, int dtype) {
       p.shift0 != 0 || p.zi != 0 || p.Ho != p.Hv || p.Wo != p.Wv || (p.Ho % 16) != 0 || (p.Wo % 16) != 0 ||
       (p.C0 % WCK) != 0 || (p.Cout % 64) != 0 || p.CoutPad < p.Cout)
     return false;
+  // 32-bit byte offsets behind buffer descriptors whose out-of-bounds marker is 2^31 (as in wgrad_plan)
+  if ((size_t)p.B * p.Hv * p.Wv * p.C0 * 4 >= (1ull << 31) || (size_t)16 * p.C0 * p.Cout * 4 >= (1ull << 31)) return false;
   const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64);
   // one workgroup per CU or more, and few enough chunks that the fixed cost per workgroup is what the tile form pays for
   // (128 channels on 128 workgroups: 44.9 us against the implicit GEMM's 45)
@@ -291,6 +293,8 @@ int conv_winograd_launch(const ConvParams& p, hipStream_t stream) {
   D3F_CHECK(p.src0 && p.w && p.out0 && (p.Hv % 16) == 0 && (p.Wv % 16) == 0 && (p.C0 % WCK) == 0 && (p.Cout % 64) == 0 &&
                 (p.mode == CONV_RAW_STATS || (p.mode == CONV_EVAL_FUSED && p.scale && p.shift)),
             "winograd conv: bad description");
+  D3F_CHECK((size_t)p.B * p.Hv * p.Wv * p.C0 * 4 < (1ull << 31) && (size_t)16 * p.C0 * p.Cout * 4 < (1ull << 31),
+            "winograd conv: tensor beyond the 2 GiB reach of its 32-bit offsets");
   ConvParams q = p;
   q.src0_bytes = (unsigned)((size_t)p.B * p.Hv * p.Wv * p.C0 * 4);
   q.w_bytes = (unsigned)((size_t)16 * p.C0 * p.Cout * 4);

@@ -138,6 +138,7 @@ class UnetEngine {
   // partials) and once in the backward pass (the (sum dz, sum dz*xhat) partials); the finalize kernels then divide by
   // rows * world.  dgamma / dbeta stay LOCAL sums (the gradient all-reduce adds them up like every other gradient).
   typedef int (*AllReduceFn)(void* ctx, float* data, int64_t count, void* stream);
+  bool bn_sync_installed() const { return bn_sync_fn_ != nullptr; }
   void set_bn_sync(AllReduceFn fn, void* ctx, int world) { bn_sync_fn_ = fn; bn_sync_ctx_ = ctx; bn_sync_world_ = world > 0 ? world : 1; }
   int export_tensor(const char* name, const void* ws, float* out_nchw, hipStream_t s) const;
   int export_shape(const char* name, int32_t dims[3]) const;

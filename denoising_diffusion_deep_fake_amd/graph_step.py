@@ -35,7 +35,7 @@ class StepBuffers(C.Structure):
 
 
 class GraphTrainStep:
-    RING = 64  # pinned slots for Adam's coefficients: the host never runs that many steps ahead of the GPU
+    RING = 64  # pinned slots for Adam's coefficients; a slot is rewritten only after the copy that read it has run
 
     def __init__(self, model, optimizer, noise_lambda, input_min=-1.0, input_max=1.0, use_graph=True):
         if not isinstance(model, Unet) or not isinstance(optimizer, FusedAdam) or optimizer.module is not model:
@@ -57,18 +57,21 @@ class GraphTrainStep:
                      noisy=torch.empty(shape, **f32), pred=torch.empty(shape, **f32), gpred=torch.empty(shape, **f32),
                      loss=torch.zeros(3, **f32),
                      loss_ws=torch.empty(L.d3f_mse_ssim_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=device),
-                     coef=torch.zeros(8, **f32), ring=torch.zeros((self.RING, 8), dtype=torch.float32).pin_memory())
+                     coef=torch.zeros(8, **f32), ring=torch.zeros((self.RING, 8), dtype=torch.float32).pin_memory(),
+                     ring_events=[None] * self.RING)
             self._bufs[key] = b
         return b
 
     @torch.no_grad()
     def __call__(self, image):
         """one optimiser step on `image` ([B,3,H,W] f32 on the HIP device, already augmented); returns the loss as a
-        device scalar (a view of the step's {loss, mse, ssim} buffer: read it before the next step overwrites it)"""
+        fresh device scalar (a stream-ordered copy: callers such as Trainer / self.log keep it across later steps);
+        `.parts` is a copy of the step's {loss, mse, ssim} buffer, which every replay overwrites"""
         m, opt = self.model, self.optimizer
-        if m._rt["grad_sync"] is not None:
+        if m._rt["grad_sync"] is not None or m._rt.get("bn_sync") is not None:
             raise D3FError("GraphTrainStep is the single-GPU form: under data parallelism the gradient buckets are "
-                           "all-reduced between the backward segments (use the eager step)")
+                           "all-reduced between the backward segments, and synchronised BatchNorm statistics call "
+                           "back into Python inside the pass (use the eager step)")
         if not m.training:
             raise D3FError("GraphTrainStep needs the model in train mode (batch statistics, gradients)")
         if image.dim() != 4 or image.shape[1] != 3 or m.in_channels != 3 or m.classes != 3:
@@ -96,11 +99,17 @@ class GraphTrainStep:
             raise NotImplementedError("FusedAdam implements plain Adam")
         opt._step += 1
         L = _lib.lib()
-        slot = b["ring"][self._slot % self.RING]
+        k = self._slot % self.RING
         self._slot += 1
+        if b["ring_events"][k] is not None:
+            b["ring_events"][k].synchronize()  # the copy that read this slot RING steps ago (normally long done)
+        slot = b["ring"][k]
         check(L.d3f_adam_coefficients(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       int(opt._step), float(opt.grad_scale), C.cast(slot.data_ptr(), C.POINTER(C.c_float))))
         b["coef"].copy_(slot, non_blocking=True)
+        if b["ring_events"][k] is None:
+            b["ring_events"][k] = torch.cuda.Event()
+        b["ring_events"][k].record()
         eng = m._engine(image.shape[0], image.shape[2], image.shape[3], dev)
         eng.serial += 1
         rt["last_engine"] = eng
@@ -113,5 +122,5 @@ class GraphTrainStep:
         rt["flat_nbt"] += 1
         eng.packed_version = None  # the step packed BEFORE its Adam update: the layouts are one update behind
         m.mark_params_changed()
-        self.parts = b["loss"]  # {loss, mse, ssim}
-        return b["loss"][0]
+        self.parts = b["loss"].clone()  # {loss, mse, ssim}
+        return self.parts[0]

@@ -130,15 +130,21 @@ class _Engine:
         import torch.distributed as dist
         ws = self.workspace
         base = ws.data_ptr()
+        dev = ws.device
+        err = self._bn_err = [None]  # the closure holds the workspace / group / this list, never the engine itself
 
         def allreduce(ctx, data, count, stream):
             try:
                 off = int(data) - base
                 view = ws[off:off + 4 * int(count)].view(torch.float32)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=None if group is True else group)
+                # order on the stream the engine names (include/d3f_hip.h: d3f_allreduce_fn), whatever torch's current is
+                cur = torch.cuda.current_stream(dev)
+                s = cur if int(stream or 0) == cur.cuda_stream else torch.cuda.ExternalStream(int(stream or 0), device=dev)
+                with torch.cuda.stream(s):
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=None if group is True else group)
                 return 0
             except Exception as e:  # surfaces as the engine's error return (a raise cannot cross the C frame)
-                self._bn_err = e
+                err[0] = e
                 return -3
         self._bn_cb = _lib.ALLREDUCE_FN(allreduce)  # kept alive with the engine
         check(L.d3f_unet_set_bn_sync(self.h, C.cast(self._bn_cb, C.c_void_p), None, int(world_size)))

@@ -15,7 +15,7 @@ def _digest():
     from denoising_diffusion_deep_fake_amd import _lib
     return _lib.source_digest()
 
-def main(out_dir, json_path, head="unknown", date=""):
+def main(out_dir, json_path, head="unknown", date="", bench_args=""):
     path = glob.glob(f"{out_dir}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
@@ -36,12 +36,14 @@ def main(out_dir, json_path, head="unknown", date=""):
         rows.append({"kernel": cls, "launches": n[cls], "mfma_pipe_busy": round(busy, 3),
                      "wave_cycles_issue_stalled": round(c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), 3),
                      "wave_cycles_parked": round(c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), 3),
-                     "mfma_mops_f32": c["SQ_INSTS_VALU_MFMA_MOPS_F32"]})
+                     "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"),
+                     "mfma_mops_bf16": c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16")})
         print(rows[-1])
-    json.dump({"source": "profiles/tools/collect_mfma.sh (6 training steps incl. warm-up, 256x256 bs16 f32; kernels "
-                         "serialised by PMC collection)", "git_head": head, "csrc_digest": _digest(), "date": date, "kernels": rows},
+    json.dump({"source": "profiles/tools/collect_mfma.sh (6 training steps incl. warm-up, 256x256 bs16 f32 unless "
+                         "bench_args says otherwise; kernels serialised by PMC collection)", "bench_args": bench_args,
+               "git_head": head, "csrc_digest": _digest(), "date": date, "kernels": rows},
               open(json_path, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

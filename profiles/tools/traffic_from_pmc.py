@@ -46,7 +46,7 @@ def durations(counter_dir):
             for r in csv.DictReader(open(path[0]))}
 
 
-def main(out_dir, traffic_json, kernels_json, head, date):
+def main(out_dir, traffic_json, kernels_json, head, date, bench_args=""):
     f, w = load(f"{out_dir}/FETCH_SIZE", "FETCH_SIZE"), load(f"{out_dir}/WRITE_SIZE", "WRITE_SIZE")
     fs, ws = steps_of(f), steps_of(w)
     n = min(len(fs), len(ws))
@@ -71,9 +71,9 @@ def main(out_dir, traffic_json, kernels_json, head, date):
                         "frac_of_8TBs": round(mb / max(us / n, 1e-9) * 1e3 / 8000.0, 3) if us else None})
     total = sum(k["hbm_MB_per_step"] for k in kernels)
     src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/tools/collect_traffic.sh over `bench.py --steps 4 "
-           "--warmup 2 --no-cpu-baseline --no-kernel-events --no-alt` (256x256, bs 16, f32); bytes = (2*FETCH_SIZE + "
+           "--warmup 2 --no-cpu-baseline --no-kernel-events --no-alt` (256x256, bs 16, f32 unless bench_args says otherwise); bytes = (2*FETCH_SIZE + "
            "WRITE_SIZE) KB per MI355X_MICROARCH.md; durations from the FETCH_SIZE pass (kernels serialised)")
-    json.dump({"source": src, "git_head": head, "csrc_digest": _digest(), "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
+    json.dump({"source": src, "bench_args": bench_args, "git_head": head, "csrc_digest": _digest(), "date": date, "steps": n, "hbm_MB_per_step_total": round(total, 1),
                "kernels": kernels}, open(kernels_json, "w"), indent=1)
     # the roofline kernel family: conv_igemm_kernel and its LDS-patch form for the 16-channel full-resolution layers
     zero = [0, 0.0, 0.0, 0.0]
@@ -95,4 +95,4 @@ def main(out_dir, traffic_json, kernels_json, head, date):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
