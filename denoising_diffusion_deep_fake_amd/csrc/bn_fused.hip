@@ -28,8 +28,7 @@ constexpr int BNF_MAX_ROWS = 1024;  // partial rows a workgroup is asked to redu
 
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   static const bool off = getenv("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
-  static const int max_rows = getenv("D3F_BN_FUSED_MAX_ROWS") ? atoi(getenv("D3F_BN_FUSED_MAX_ROWS")) : BNF_MAX_ROWS;  // tuning knob
-  return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= max_rows;
+  return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= BNF_MAX_ROWS;
 }
 
 // sums the partial rows [rows][ld][2] of channels [c0, c0 + 32) in f64: thread (rl = tid / 16, q = tid % 16) owns the
@@ -175,8 +174,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 // per step at 64 / 128 / 192 / 256 / 320 / 512 / 768 -- every workgroup repeats the slab reduce, fewer of them repeat it
 // less; bf16 4.83 / 4.58 / 4.55 at 128 / 256 / 512: half the bytes per row, the streaming part wants the parallelism)
 static long rows_per_block_for(long rows, int slabs, int dtype) {
-  static const long knob = getenv("D3F_BN_FUSED_WGS") ? std::max(64, atoi(getenv("D3F_BN_FUSED_WGS"))) : 0;  // tuning knob
-  const long wgs = knob ? knob : (dtype == D3F_F32 ? 256 : 512);
+  const long wgs = dtype == D3F_F32 ? 256 : 512;
   long rb = std::max(1L, wgs / slabs);
   long rpb = (rows + rb - 1) / rb;
   rpb = (rpb + 31) / 32 * 32;

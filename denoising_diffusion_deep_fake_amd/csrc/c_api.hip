@@ -84,8 +84,7 @@ static Geo geo(int dtype, const d3f_conv_desc* d) {
 }
 
 static bool desc_upfold(int dtype, const d3f_conv_desc* d) {
-  static const bool off = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob (same as the engine's)
-  return !off && upfold_applies(sdt(dtype), d->upsample0, d->KH, d->stride, d->pad, d->C0, d->C1);
+  return upfold_applies(sdt(dtype), d->upsample0, d->KH, d->stride, d->pad, d->C0, d->C1);
 }
 
 static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk = false) {
@@ -452,7 +451,7 @@ size_t d3f_conv_backward_weight_workspace_bytes(int dtype, const d3f_conv_desc* 
   if (wgrad_params(dtype, d, w) != 0) return 0;
   WgradLayer L;
   if (wgrad_layer_plan(L, w, sdt(dtype)) != 0) return 0;
-  return std::max(wgrad_partial_floats(w), wgrad_layer_partial_floats(L)) * sizeof(float);
+  return wgrad_layer_partial_floats(L) * sizeof(float);
 }
 int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, const void* src0,
                              const void* src1, void* workspace, float* dw, void* stream) {
@@ -464,20 +463,11 @@ int d3f_conv_backward_weight(int dtype, const d3f_conv_desc* d, const void* dy, 
     return 0;
   }
   D3F_CHECK(dy && src0 && workspace && dw && (d->C1 == 0 || src1), "conv_backward_weight: null argument");
-  {  // the passes the engine runs for this layer (class form behind an up-sampling where it applies)
-    WgradLayer L;
-    if (int rc = wgrad_layer_plan(L, w, sdt(dtype))) return rc;
-    if (L.part[0].part != WG_WHOLE)
-      return wgrad_layer_launch(L, dy, src0, src1, reinterpret_cast<float*>(workspace), dw, d->Cout, d->CinReal, dtype,
-                                (hipStream_t)stream);
-  }
-  w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = reinterpret_cast<float*>(workspace);
-  if (int rc = wgrad_launch(w, dtype, (hipStream_t)stream)) return rc;
-  WgradDst dst;
-  dst.n = 1;
-  dst.dw[0] = dw;
-  return wgrad_reduce_launch(w.partial, w.splits, w.Cout, d->Cout, d->C0 + d->C1, d->CinReal, d->KH, d->KW,
-                             dst, (hipStream_t)stream);
+  // the passes the engine runs for this layer (class form behind an up-sampling where it applies), then its slab reduce
+  WgradLayer L;
+  if (int rc = wgrad_layer_plan(L, w, sdt(dtype))) return rc;
+  return wgrad_layer_launch(L, dy, src0, src1, reinterpret_cast<float*>(workspace), dw, d->Cout, d->CinReal, dtype,
+                            (hipStream_t)stream);
 }
 
 int d3f_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma,

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace d3f {
 
@@ -170,7 +171,6 @@ struct ConvParams {
                        // forward of conv(cat(upsample2x(src0), src1)) with the up-sampling folded into pre-summed
                        // weights: 3 (src0 is then described at its own low resolution H0s x W0s, shift0 = 0)
   int nz;              // classes in the launch (grid.z), filled by plan: 4 for par 1 / 3, else 1
-  int xcd_swizzle;     // XCD-aware workgroup order (filled by plan)
   int KH, KW, stride, pad;
   int M;               // B*Ho*Wo
   int tiles_m, tiles_n;
@@ -203,8 +203,9 @@ struct ConvTile {
 // Does conv(cat(upsample2x(x0), x1)) run with the up-sampling folded into pre-summed weights (ConvParams::par == 3
 // forward, 4x4 stride-2 data gradient)?  Needs whole k-tiles per tap in both sources.
 static inline bool upfold_applies(int dtype, int upsample0, int k, int stride, int pad, int C0, int C1) {
+  static const bool off = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob: gather through the up-sampling
   const int bke = dtype == D3F_BF16 ? 64 : 32;
-  return upsample0 && k == 3 && stride == 1 && pad == 1 && C0 > 0 && (C0 % bke) == 0 && (C1 % bke) == 0;
+  return !off && upsample0 && k == 3 && stride == 1 && pad == 1 && C0 > 0 && (C0 % bke) == 0 && (C1 % bke) == 0;
 }
 // Does the data gradient of this convolution run as the parity-class decomposition (ConvParams::par)?  The weight
 // packers (pointwise.hip) store the flipped taps class by class exactly when it does, so both ask this one function.
@@ -248,7 +249,6 @@ struct WgradParams {
   int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;
   int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
-  int xcd_swizzle;  // tap-parallel kernel: XCD-aware workgroup order (filled by plan)
   double flops;  // algorithmic FLOPs of this launch, for profiling
   // Which part of the layer's gradient this launch computes (set before wgrad_plan; everything below is filled by it):
   //   WG_WHOLE  every input channel, KH*KW taps (the ordinary launch);
@@ -263,42 +263,19 @@ struct WgradParams {
   int slab_cin;   // input channels the launch covers = row width of its slabs
   int slab_taps;  // taps per slab row block: KH*KW, or 16 folded taps
   int Mi, Hc, Wc; // pixel grid the k-loop iterates: (M, Ho, Wo), or one parity class (M/4, H0s, W0s)
-  int step_img, step_row, step_col;  // one k-chunk (kp pixels) as whole images + rows + columns of that grid
-  int kp;         // pixels per k-chunk of the chosen kernel form: 32, or 128 for the slim 32x32 k-split tile
+  int step_img, step_row, step_col;  // one k-chunk (32 pixels) as whole images + rows + columns of that grid
 };
 enum WgradPart : int { WG_WHOLE = 0, WG_CLASS = 1, WG_SKIP = 2 };
-// Grouped launches: layers of identical shape (the 3x3 stride-1 convolutions inside one ResNet stage) run their
-// weight gradients as ONE launch, blockIdx.z = member.  With G members there are G times as many (tap, co, ci)
-// tiles to spread over the chip, so the pixel range is cut into G times fewer slabs: less partial-slab traffic,
-// fewer and longer launches.  Member z reads dy[z] / src0[z] and writes its slabs at partial + z * splits * |W|.
-constexpr int WG_MAXG = 12;
-struct WgradGroup {
-  const void* dy[WG_MAXG];
-  const void* src0[WG_MAXG];
-  int n;
-};
-struct WgradDst {
-  float* dw[WG_MAXG];
-  int n;
-};
-// fills splits/tiles for a launch of `group` identical layers; returns 0
-int wgrad_plan(WgradParams& p, int dtype, int group = 1);
-size_t wgrad_partial_floats(const WgradParams& p);  // per group member
-int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);  // one layer: p.dy / p.src0 / p.src1
-int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hipStream_t stream);
-// sums the slabs [member][splits][CoutP][KH*KW][Cin] in a fixed order and writes each member's PyTorch-layout
-// gradient [Cout][CinReal][KH][KW] (fp32), dropping padded channels; one launch for the whole group
-int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
-                        int KH, int KW, const WgradDst& dst, hipStream_t stream);
-// the general form: the slabs cover `Cin` channels (`CinRealPart` of them real) that land at channel `c_off` of a
-// gradient with `CinRealTotal` input channels; fold != 0: slabs hold 16 folded taps per filter (WG_CLASS), summed
-// into the 3x3 taps they belong to
-int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
-                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
-                             hipStream_t stream);
+// fills splits / tiles / extents for one launch; returns 0
+int wgrad_plan(WgradParams& p, int dtype);
+size_t wgrad_partial_floats(const WgradParams& p);
+int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);  // p.dy / p.src0 / p.src1 -> slabs in p.partial
 
-// Deferred slab reduces: jobs collected while a gradient bucket's weight-gradient kernels are launched, run as ONE
-// kernel at the end of the bucket (every layer then owns its slab region instead of sharing one scratch).
+// Slab reduces: the slabs [splits][CoutP][taps][Cin] are summed in a fixed order and written as the PyTorch-layout
+// gradient [Cout][CinReal][KH][KW] (fp32), dropping padded channels.  A job's slabs cover `Cin` channels (`CinReal` of
+// them real) that land at channel `c_off` of a gradient with `CinTot` input channels; fold != 0: the slabs hold 16
+// folded taps per filter (WG_CLASS), summed into the 3x3 taps they belong to.  The jobs of one layer (1 or 2 passes)
+// run as ONE launch.
 constexpr int WG_BATCH = 20;
 struct WgradReduceJob {
   const float* partial;
@@ -321,10 +298,10 @@ struct WgradLayer {
 };
 // base: geometry of the layer (B, Hv, Wv, C0, C1, H0s, W0s, shift0, Ho, Wo, Cout (padded), KH, KW, stride, pad, M, flops)
 int wgrad_layer_plan(WgradLayer& L, const WgradParams& base, int dtype);
-size_t wgrad_layer_partial_floats(const WgradLayer& L);  // slab scratch: the passes are stream-ordered, so the max
+size_t wgrad_layer_partial_floats(const WgradLayer& L);  // slab scratch: every pass keeps its own region
 int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                        float* dw, int CoutReal, int CinReal, int dtype, hipStream_t stream);
-size_t wgrad_layer_partial_floats_all(const WgradLayer& L);  // slab scratch when every pass keeps its slabs (deferred)
+// the passes' launches only; their reduce jobs are appended to `tb` for wgrad_reduce_batch_launch on the same stream
 int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                                 float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
                                 hipStream_t stream);

@@ -271,21 +271,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WGM * WGN), wmn = wave % (WGM * WGN);
   const int wm = wmn / WGN, wn = wmn % WGN;
-  // XCD-aware workgroup order (speed only): consecutive block ids are dealt round-robin over the 8 XCDs (private L2s),
-  // so the tiles_n workgroups that gather the SAME activation rows -- and neighbouring m-tiles, which share halo rows --
-  // each pulled them into a different L2.  The bijective remap (cdna_hip_programming.md T1) gives every XCD a
-  // contiguous range of the logical order (n-tile fastest, then m-tile, k-slice, class).
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.xcd_swizzle) {
-    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
-    const unsigned orig = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
-    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
-    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    bx = wgid % gx;
-    const unsigned rest = wgid / gx;
-    by = rest % gy;
-    bz = rest / gy;
-  }
+  // Workgroups in plain dispatch order: an XCD-aware remap (every XCD a contiguous range of tiles) cut this kernel's
+  // L2-miss traffic by 12 % but made it 2 % SLOWER (bands of unequal length per XCD; profiles/README.md round 2)
+  const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int tile_n = (int)bx % p.tiles_n, tile_m = (int)bx / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int chunk = tid & 7, rbase = tid >> 3;
@@ -1469,9 +1457,8 @@ static ConvTile pick_tile(const ConvParams& p, bool x3, bool bf16 = false) {
   // per step and their slab traffic leave the caller's stream
   // bf16 storage defaults to 2: its MFMA work is a quarter, the 32x32 tile's L2 -> LDS traffic (302 MB per layer3
   // launch) is what it waits for -- r03 sweep 4.62 / 4.58 / 4.42 / 4.53 ms per step for modes 0 / 1 / 2 / 3
-  static const int ksplit_knob = getenv("D3F_KSPLIT_TILES") ? atoi(getenv("D3F_KSPLIT_TILES")) : -1;
-  const int ksplit_mode = ksplit_knob >= 0 ? ksplit_knob : (bf16 ? 2 : 3);
-  if (!x3 && ksplit_mode > 0 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
+  const int ksplit_mode = bf16 ? 2 : 3;
+  if (!x3 && co % 32 == 0 && p.mode != CONV_HEAD_NCHW) {
     const long b64 = blocks(64, 64);
     if (b64 < 192 || (b64 < 384 && ksplit_mode == 3)) return {32, 32};
     if (b64 < 384 && ksplit_mode == 2) return {64, 32};
@@ -1538,11 +1525,6 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3, dtype == D3F_BF16);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);
-  // tuning knob D3F_XCD_SWIZZLE: letters i (this kernel) / w (weight gradient).  Measured: the remap cuts this
-  // kernel's L2-miss traffic by 12 % but makes it 2 % SLOWER (every XCD then works on one contiguous band of rows
-  // and the bands' lengths differ), so it is off here by default and on for the weight gradient only
-  static const char* swz = getenv("D3F_XCD_SWIZZLE");
-  p.xcd_swizzle = (swz != nullptr && strchr(swz, 'i') != nullptr) ? 1 : 0;
   p.splitk = 1;
   p.stat_rows = p.nz * p.tiles_m;
   // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop

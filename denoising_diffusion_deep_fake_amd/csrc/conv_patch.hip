@@ -23,9 +23,13 @@ namespace d3f {
 
 constexpr int CP_PH = 4, CP_PW = 64;  // output tile (rows x columns); 256 rows of the implicit GEMM
 
-bool conv_patch_applies(const ConvParams& p, int dtype) {
+static bool patch_conv_off() {
   static const bool off = getenv("D3F_NO_PATCH_CONV") != nullptr;  // debugging knob: the implicit-GEMM path instead
-  if (off || (dtype != D3F_F32 && dtype != D3F_BF16)) return false;
+  return off;
+}
+
+bool conv_patch_applies(const ConvParams& p, int dtype) {
+  if (patch_conv_off() || (dtype != D3F_F32 && dtype != D3F_BF16)) return false;
   const bool mode_ok = p.mode == CONV_RAW_STATS || p.mode == CONV_HEAD_NCHW ||
                        (p.mode == CONV_EVAL_FUSED && p.res == nullptr) ||
                        (p.mode == CONV_DGRAD && p.out_c0 == p.Cout && (p.Cout % 4) == 0);
@@ -350,8 +354,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 constexpr int ST_PH = 8, ST_PW = 32, ST_BN = 32;
 
 bool conv_stem_applies(const ConvParams& p, int dtype) {
-  static const bool off = getenv("D3F_NO_PATCH_CONV") != nullptr;
-  if (off || dtype != D3F_F32) return false;
+  if (patch_conv_off() || dtype != D3F_F32) return false;
   const bool mode_ok = (p.mode == CONV_RAW_STATS) || (p.mode == CONV_EVAL_FUSED && p.res == nullptr);
   return mode_ok && p.par == 0 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.C0 == 4 && p.C1 == 0 &&
          p.shift0 == 0 && p.zi == 0 && (p.Cout % ST_BN) == 0 && p.Hv == 2 * p.Ho && p.Wv == 2 * p.Wo &&
@@ -506,7 +509,6 @@ void conv_patch_plan(ConvParams& p, int dtype) {
     p.patch = 2;
     p.nz = 1;
     p.splitk = 1;
-    p.xcd_swizzle = 0;
     p.w_ld = p.Kpad;
     p.tiles_m = p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW);
     p.tiles_n = p.Cout / ST_BN;
@@ -516,7 +518,6 @@ void conv_patch_plan(ConvParams& p, int dtype) {
   p.patch = dtype == D3F_BF16 ? 3 : 1;  // 3: the bf16-storage instantiation
   p.nz = 1;
   p.splitk = 1;
-  p.xcd_swizzle = 0;
   p.w_ld = p.Kpad;
   p.tiles_m = p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW);
   p.tiles_n = 1;

@@ -21,7 +21,7 @@
 
 namespace d3f {
 
-constexpr int KP = 32;  // pixels per k-chunk (the kernel's KPX; WgradParams::kp carries the launch's value)
+constexpr int KP = 32;  // pixels per k-chunk
 
 // store one 16-byte global vector (4 f32 or 8 bf16) as f32 into LDS
 template <typename T> __device__ __forceinline__ void lds_store_as_f32(float* dst, const uint4& v);
@@ -70,16 +70,9 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // neighbourhood); the k-loop runs over the LOW-resolution pixel grid (b, j, i): dY is read at (2j + py, 2i + px), the
 // source at (j + a - 1 + py, i + b - 1 + px) -- the low-resolution pixel under up-sampled row 2j + py + kh - 1 for the
 // taps kh that share `a` (kh = 0 | 1,2 for py = 0; kh = 0,1 | 2 for py = 1; columns alike).
-//
-// KPX: pixels per k-chunk.  32 everywhere except the "slim" form of the wide layers (32x32 tile, the four waves
-// splitting each 128-pixel chunk): per workgroup it writes a 4 KB slab instead of the 64x64 tile's 16 KB, so at the
-// same workgroup count the slab traffic (and the reduce pass that re-reads it) is a quarter, for twice the L2 -> LDS
-// staging per MFMA; 16 MFMAs per wave between barriers in both forms.
-template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false, int KPX = 32>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, const WgradGroup grp) {
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
-  constexpr int KP = KPX;  // shadows the namespace constant: everything below counts in this kernel's chunk
-  static_assert(!X3 || KPX == 32, "x3 staging is laid out for 32-pixel chunks");
 
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
@@ -107,17 +100,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   // the SAME dY rows and nearly the same X rows, but consecutive block ids are dealt round-robin over the 8 XCDs, each
   // with its own L2 -- every slab was fetched by up to 8 L2s (layer1: 256 MB per launch against 34 MB of operands).
   // The bijective remap of cdna_hip_programming.md T1 gives every XCD a contiguous range of the logical order
-  // (x fastest, then slab, then group member), so a slab's workgroups share one L2.
-  int bid = blockIdx.x, split = blockIdx.y, member = blockIdx.z;
-  if (p.xcd_swizzle) {
-    const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  // (x fastest, then slab), so a slab's workgroups share one L2 (its L2-miss traffic 4.13 -> 1.29 GB per step, r02_t).
+  int bid, split;
+  {
+    const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const unsigned orig = blockIdx.y * gx + blockIdx.x;
     const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
     const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     bid = (int)(wgid % gx);
-    const unsigned rest = wgid / gx;
-    split = (int)(rest % gridDim.y);
-    member = (int)(rest / gridDim.y);
+    split = (int)(wgid / gx);
   }
   const int tile_ci = bid % p.tiles_ci;
   bid /= p.tiles_ci;
@@ -131,12 +122,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
   const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;  // ci0: channel offset inside this launch's channel range
   const int Cin = p.slab_cin;
 
-  // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip); blockIdx.z = group member
-  const void* const dy_ptr = grp.dy[member];
-  const void* const src0_ptr = grp.src0[member];
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy_ptr, p.dy_bytes);
-  const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(src0_ptr, p.src0_bytes);
-  const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : src0_ptr, p.src1_bytes);
+  // buffer descriptors: out-of-range lanes read zeros in hardware (see conv_igemm.hip)
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx0 = make_rsrc(p.src0, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.src1 != nullptr ? p.src1 : p.src0, p.src1_bytes);
 
   // loader roles: every thread owns ONE pixel row of the chunk (lrow) and the 16-byte vectors lcol + j * TPR of it, in
   // both operands -- one pixel decode and one validity test per thread and chunk serve all of its loads.  (On gfx950
@@ -342,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, co
 
   // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int taps = p.slab_taps;
-  float* __restrict__ slab = p.partial + ((long)member * p.splits + split) * p.Cout * taps * Cin;
+  float* __restrict__ slab = p.partial + (long)split * p.Cout * taps * Cin;
   if (KSPLIT > 1) {
     // the 4 waves hold partial sums of the same 32x32 tile: reduce through LDS
     float* red = lds;
@@ -454,20 +443,9 @@ __device__ __forceinline__ void wgrad_reduce_body(float* row, const float* __res
   }
 }
 
-template <bool FOLD>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int CoutP,
-                                                           int Cin, int CinReal, int taps, int CB, int nsg, int VB,
-                                                           const WgradDst dst, int CinTot, int c_off) {
-  extern __shared__ __attribute__((aligned(16))) float row[];  // [nsg][taps][CB + 1]
-  const int member = blockIdx.y;
-  wgrad_reduce_body<FOLD>(row, partial + (long)member * splits * CoutP * taps * Cin, splits, CoutP, Cin, CinReal, taps, CB,
-                          nsg, VB, dst.dw[member], CinTot, c_off, blockIdx.x, blockIdx.z * CB);
-}
-
-// Several layers' slab reduces as ONE launch (every layer keeps its own slabs until the end of its gradient bucket):
-// 47 launches of 5-30 us per step, each a short HBM-bound burst in the middle of the weight-gradient stream, become one
-// launch per bucket.  A workgroup finds its job in the table by its block index; the summation order inside a job is
-// the single-layer kernel's (bitwise the same gradients).
+// The slab reduces of one layer (one job per pass: whole layer, or class-form part + skip part) as ONE launch.  A
+// workgroup finds its job in the table by its block index.  (One launch per gradient BUCKET -- every layer keeping its
+// slabs until then -- was measured equal or slightly slower per step, profiles/README.md round 3.)
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatch tb) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   int j = 0;
@@ -484,25 +462,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedu
                              q.c_off, co, cz * q.CB);
 }
 
-struct WTile {
-  int bm, bn, kp;
-};
-static WTile pick_wtile(const WgradParams& p, int dtype) {
-  const int cin = p.C0 + p.C1;
-  if (const char* f = getenv("D3F_WGRAD_TILE")) {  // tuning knob
-    const int t = atoi(f);
-    if ((t == 128 || t == 64 || t == 32) && (p.C1 == 0 || p.C0 % t == 0)) return {t, t, 32};
-  }
-  // measured per layer of Unet(resnet34) at B=16, 256x256 (profiles/README.md, r01_h): with ~1024 blocks the
-  // 64x64 tile beats 128x128 on every wide layer (fewer split slabs to write and re-read), by 15-20%
-  if (p.Cout > 32 && cin > 32) {
-    // slim form (fp32 storage): 32x32 tile, 128-pixel chunks split over the four waves -- a quarter of the slab bytes.
-    // D3F_WGRAD_SLIM=<min channels>: layers with at least that many filters take it (0 / unset: none)
-    static const int slim_from = getenv("D3F_WGRAD_SLIM") ? atoi(getenv("D3F_WGRAD_SLIM")) : 0;
-    if (dtype == D3F_F32 && slim_from > 0 && p.Cout >= slim_from && (p.C1 == 0 || p.C0 % 32 == 0)) return {32, 32, 128};
-    return {64, 64, 32};
-  }
-  return {32, 32, 32};
+// tile edge (co x ci) of the tap-parallel kernel.  Measured per layer of Unet(resnet34) at B=16, 256x256
+// (profiles/README.md): with ~1024 workgroups the 64x64 tile beats 128x128 on every wide layer by 15-20 % (fewer split
+// slabs to write and re-read, r01_h); a 32x32 tile over 128-pixel chunks (a quarter of the slab bytes) is much slower
+// (twice the L2 -> LDS staging per MFMA, r03)
+static int pick_wtile(const WgradParams& p) { return (p.Cout > 32 && p.C0 + p.C1 > 32) ? 64 : 32; }
+static bool patch_wgrad_off() {
+  static const bool off = getenv("D3F_NO_PATCH_WGRAD") != nullptr;  // debugging knob: the tap-parallel kernel everywhere
+  return off;
 }
 
 int wgrad_patch_variant(const WgradParams& p, int dtype);
@@ -515,19 +482,16 @@ bool wgrad_class_applies(const WgradParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_WGRAD_CLASS") != nullptr;  // debugging knob: nine taps through the up-sampling
   if (off || !p.shift0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
   if (p.Ho != p.Hv || p.Wo != p.Wv || p.H0s * 2 != p.Hv || p.W0s * 2 != p.Wv) return false;
-  if (getenv("D3F_NO_PATCH_WGRAD") == nullptr) {
+  if (!patch_wgrad_off()) {
     // the narrow decoder layers (persistent patch kernel, conv_wgrad_patch.hip): its class form takes variants 1 and 3
-    // with whole 32-channel slices per source (D3F_NO_PATCH_CLASS: the nine-tap patch kernel, for the A/B)
+    // with whole 32-channel slices per source
     const int v = wgrad_patch_variant(p, dtype);
-    static const bool no_pc = getenv("D3F_NO_PATCH_CLASS") != nullptr;
-    if (v) return !no_pc && (v == 1 || v == 3) && (p.C0 % 32) == 0 && (p.C1 % 32) == 0 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0;
+    if (v) return (v == 1 || v == 3) && (p.C0 % 32) == 0 && (p.C1 % 32) == 0 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0;
   }
-  const WTile t = pick_wtile(p, dtype);
-  return (t.bm == 64 || t.kp == 128) && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
+  return pick_wtile(p) == 64 && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
 }
 
-int wgrad_plan(WgradParams& p, int dtype, int group) {
-  D3F_CHECK(group >= 1 && group <= WG_MAXG, "wgrad: group of %d layers", group);
+int wgrad_plan(WgradParams& p, int dtype) {
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "wgrad: bad dtype %d", dtype);
   const int ve = dtype == D3F_F32 ? 4 : 8;
   const long es = dtype == D3F_F32 ? 4 : 2;
@@ -536,9 +500,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   D3F_CHECK(p.H0s == (p.Hv >> p.shift0) && p.W0s == (p.Wv >> p.shift0), "wgrad: src0 extent");
   D3F_CHECK(p.M == p.B * p.Ho * p.Wo, "wgrad: M");
   D3F_CHECK(p.part == WG_WHOLE || p.part == WG_CLASS || p.part == WG_SKIP, "wgrad: part %d", p.part);
-  const WTile t = pick_wtile(p, dtype);
-  p.kp = t.kp;
-  D3F_CHECK(p.C1 == 0 || (p.C0 % t.bn) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t.bn);
+  const int t = pick_wtile(p);
+  D3F_CHECK(p.C1 == 0 || (p.C0 % t) == 0, "wgrad: C0=%d must be a multiple of the ci tile %d", p.C0, t);
   const long bdy = (long)p.M * p.Cout * es, b0 = (long)p.B * p.H0s * p.W0s * p.C0 * es,
              b1 = (long)p.B * p.Hv * p.Wv * p.C1 * es;
   D3F_CHECK(bdy < (1L << 31) && b0 < (1L << 31) && b1 < (1L << 31), "wgrad: operand larger than 2 GiB");
@@ -551,9 +514,8 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
   p.Hc = p.cls ? p.H0s : p.Ho;
   p.Wc = p.cls ? p.W0s : p.Wo;
   p.Mi = p.B * p.Hc * p.Wc;
-  p.patch = getenv("D3F_NO_PATCH_WGRAD") ? 0 : wgrad_patch_variant(p, dtype);
-  if (p.part != WG_WHOLE) D3F_CHECK(group == 1 && wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
-  D3F_CHECK(group == 1 || (p.patch == 0 && p.C1 == 0), "wgrad: only plain single-source layers are grouped");
+  p.patch = patch_wgrad_off() ? 0 : wgrad_patch_variant(p, dtype);
+  if (p.part != WG_WHOLE) D3F_CHECK(wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
     int gx, gy;
     wgrad_patch_grid(p, p.patch, &gx, &gy);
@@ -562,26 +524,23 @@ int wgrad_plan(WgradParams& p, int dtype, int group) {
     p.tiles_co = p.tiles_ci = 0;
     return 0;
   }
-  {  // one k-chunk (kp pixels) in units of the iterated grid
-    const int hw = p.Hc * p.Wc, rem = p.kp % hw;
-    p.step_img = p.kp / hw;
+  {  // one k-chunk (KP pixels) in units of the iterated grid
+    const int hw = p.Hc * p.Wc, rem = KP % hw;
+    p.step_img = KP / hw;
     p.step_row = rem / p.Wc;
     p.step_col = rem % p.Wc;
   }
-  p.tiles_co = cdiv(p.Cout, t.bm);
-  p.tiles_ci = cdiv(p.slab_cin, t.bn);
-  const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps * group;
-  const int total_chunks = cdiv(p.Mi, p.kp);
-  long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
-  if (const char* f = getenv("D3F_WGRAD_BLOCKS")) target = std::max(1, atoi(f));  // tuning knob
+  p.tiles_co = cdiv(p.Cout, t);
+  p.tiles_ci = cdiv(p.slab_cin, t);
+  const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps;
+  const int total_chunks = cdiv(p.Mi, KP);
+  const long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
   long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.chunks_per_split = cdiv(total_chunks, splits);
   p.splits = cdiv(total_chunks, p.chunks_per_split);
-  static const char* swz = getenv("D3F_XCD_SWIZZLE");  // tuning knob: letters i (conv_igemm) / w (this kernel); default w
-  p.xcd_swizzle = (swz == nullptr || strchr(swz, 'w') != nullptr) ? 1 : 0;
   return 0;
 }
 
@@ -589,47 +548,27 @@ size_t wgrad_partial_floats(const WgradParams& p) {
   return (size_t)p.splits * p.Cout * p.slab_taps * p.slab_cin;
 }
 
+// (Wave slots, not priorities: these launches run at the lowest stream priority NEXT to the dependent BatchNorm ->
+// data-gradient chain; an occupancy cap through unused dynamic LDS was measured slower, profiles/README.md round 2.)
 template <typename T>
-static void wgrad_launch_t(const WgradParams& p, const WgradGroup& g, int bm, dim3 grid, hipStream_t stream, bool x3) {
+static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream, bool x3) {
   const dim3 block(256);
-  // Occupancy cap: unused dynamic LDS on top of the kernel's static tile.  The weight gradients run at the lowest
-  // priority NEXT to the dependent BatchNorm -> data-gradient chain; priority only decides which queue a FREE slot
-  // goes to, so if these workgroups fill every wave slot of every CU the chain's kernels wait for them to drain.
-  static const int lds_pad = getenv("D3F_WGRAD_LDS_PAD") ? atoi(getenv("D3F_WGRAD_LDS_PAD")) : 0;
-  if (bm == 128) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
-  } else if (bm == 64) {
-    static const bool widen = getenv("D3F_BF16_WGRAD_F32") != nullptr;  // bf16 storage: old widening form (tuning knob)
-    if (x3 || (sizeof(T) == 2 && !widen)) {
-      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, true>), grid, block, lds_pad, stream, p, g);
-      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, lds_pad, stream, p, g);
+  if (bm == 64) {
+    if (x3 || sizeof(T) == 2) {  // f32x3, and bf16 storage on the native bf16 MFMA
+      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
       return;
     }
-    if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true>), grid, block, lds_pad, stream, p, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, lds_pad, stream, p, g);
-  } else if (p.kp == 128) {
-    if constexpr (sizeof(T) == 4) {
-      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false, true, 128>), grid, block, lds_pad, stream, p, g);
-      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false, false, 128>), grid, block, lds_pad, stream, p, g);
-    }
+    if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, lds_pad, stream, p, g);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, 0, stream, p);
   }
 }
 
 int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
-  WgradGroup g;
-  g.n = 1;
-  g.dy[0] = p.dy;
-  g.src0[0] = p.src0;
-  return wgrad_launch_group(p, g, dtype, stream);
-}
-
-int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hipStream_t stream) {
   if (p.M == 0) return 0;
-  D3F_CHECK(g.n >= 1 && g.n <= WG_MAXG, "wgrad: group of %d layers", g.n);
   if (p.patch) {
-    D3F_CHECK(g.n == 1 && g.dy[0] == p.dy && g.src0[0] == p.src0, "wgrad: the patch kernel takes one layer");
     const bool prof = prof_enabled(PROF_WGRAD);
     if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
     // (the persistent patch kernel of the narrow layers stays on the fp32 MFMA in f32x3 mode)
@@ -637,36 +576,28 @@ int wgrad_launch_group(const WgradParams& p, const WgradGroup& g, int dtype, hip
     if (prof) prof_end(stream);
     return rc;
   }
-  const WTile t = pick_wtile(p, dtype == D3F_F32X3 ? D3F_F32 : dtype);
-  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t.bm) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1 && p.kp == t.kp,
-            "wgrad: params were not planned");
-  D3F_CHECK(!p.cls || t.bm == 64 || t.kp == 128, "wgrad: class form needs the 64x64 or the slim tile");
-  // (like the patch kernels, the slim tile stays on the fp32 MFMA in f32x3 mode)
-  D3F_CHECK(t.kp == 32 || dtype != D3F_BF16, "wgrad: the slim tile is an fp32-storage form");
-  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits, (unsigned)g.n);
+  const int t = pick_wtile(p);
+  D3F_CHECK(p.tiles_co == cdiv(p.Cout, t) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1, "wgrad: params were not planned");
+  D3F_CHECK(!p.cls || t == 64, "wgrad: class form needs the 64x64 tile");
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits);
   const bool prof = prof_enabled(PROF_WGRAD);
-  if (prof) prof_begin(PROF_WGRAD, p.flops * g.n, stream);
-  if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, g, t.bm, grid, stream, false);
-  else wgrad_launch_t<float>(p, g, t.bm, grid, stream, dtype == D3F_F32X3);
+  if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
+  if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, t, grid, stream, false);
+  else wgrad_launch_t<float>(p, t, grid, stream, dtype == D3F_F32X3);
   if (prof) prof_end(stream);
   D3F_HIP(hipGetLastError());
   return 0;
 }
 
-int wgrad_reduce_launch(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinReal,
-                        int KH, int KW, const WgradDst& dst, hipStream_t stream) {
-  return wgrad_reduce_launch_part(partial, splits, CoutP, Cout, Cin, CinReal, CinReal, 0, KH, KW, 0, dst, stream);
-}
-
 // work split of one reduce: channel chunks (cz of CB channels), slab groups (nsg) and vector columns (VB) per workgroup
 static int wgrad_reduce_job(WgradReduceJob& q, const float* partial, int splits, int CoutP, int Cout, int Cin,
-                            int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw, int members) {
+                            int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw) {
   D3F_CHECK(Cin % 4 == 0 && CinRealPart <= Cin && Cout <= CoutP && c_off + CinRealPart <= CinRealTotal &&
                 (!fold || (KH == 3 && KW == 3)),
             "wgrad reduce: arguments");
   const int taps = fold ? 16 : KH * KW;
   int cz = 1;  // channel chunks: enough workgroups to fill the chip, chunks of at least 16 channels (64-byte segments)
-  while ((long)Cout * members * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
+  while ((long)Cout * cz < 512 && Cin % (cz * 2) == 0 && Cin / (cz * 2) >= 16 && (Cin / (cz * 2)) % 4 == 0) cz *= 2;
   const int CB = Cin / cz, nvec = taps * CB / 4;
   int nsg = nvec >= 256 ? 1 : 256 / nvec;  // slab groups: fill the 256 threads, every group gets >= 2 slabs
   if (nsg > 8) nsg = 8;
@@ -681,30 +612,11 @@ static int wgrad_reduce_job(WgradReduceJob& q, const float* partial, int splits,
   return 0;
 }
 
-int wgrad_reduce_launch_part(const float* partial, int splits, int CoutP, int Cout, int Cin, int CinRealPart,
-                             int CinRealTotal, int c_off, int KH, int KW, int fold, const WgradDst& dst,
-                             hipStream_t stream) {
-  D3F_CHECK(dst.n >= 1 && dst.n <= WG_MAXG, "wgrad reduce: %d group members", dst.n);
-  WgradReduceJob q;
-  if (int rc = wgrad_reduce_job(q, partial, splits, CoutP, Cout, Cin, CinRealPart, CinRealTotal, c_off, KH, KW, fold,
-                                dst.dw[0], dst.n))
-    return rc;
-  const dim3 grid((unsigned)Cout, (unsigned)dst.n, (unsigned)q.cz);
-  if (fold)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, grid, dim3(256), (size_t)q.lds, stream, partial, splits, CoutP, Cin,
-                       CinRealPart, q.taps, q.CB, q.nsg, q.VB, dst, CinRealTotal, c_off);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, grid, dim3(256), (size_t)q.lds, stream, partial, splits, CoutP, Cin,
-                       CinRealPart, q.taps, q.CB, q.nsg, q.VB, dst, CinRealTotal, c_off);
-  D3F_HIP(hipGetLastError());
-  return 0;
-}
-
 int wgrad_reduce_batch_add(WgradReduceBatch& tb, const float* partial, int splits, int CoutP, int Cout, int Cin,
                            int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw) {
   D3F_CHECK(tb.n < WG_BATCH, "wgrad reduce batch: table full");
   WgradReduceJob& q = tb.job[tb.n];
-  if (int rc = wgrad_reduce_job(q, partial, splits, CoutP, Cout, Cin, CinRealPart, CinRealTotal, c_off, KH, KW, fold, dw, 1))
+  if (int rc = wgrad_reduce_job(q, partial, splits, CoutP, Cout, Cin, CinRealPart, CinRealTotal, c_off, KH, KW, fold, dw))
     return rc;
   q.block0 = tb.blocks;
   tb.blocks += q.Cout * q.cz;
@@ -736,23 +648,17 @@ int wgrad_layer_plan(WgradLayer& L, const WgradParams& base, int dtype) {
     }
   }
   for (int i = 0; i < L.nparts; ++i)
-    if (int rc = wgrad_plan(L.part[i], dtype, 1)) return rc;
+    if (int rc = wgrad_plan(L.part[i], dtype)) return rc;
   return 0;
 }
 
 size_t wgrad_layer_partial_floats(const WgradLayer& L) {
   size_t n = 0;
-  for (int i = 0; i < L.nparts; ++i) n = std::max(n, wgrad_partial_floats(L.part[i]));
-  return n;
-}
-
-size_t wgrad_layer_partial_floats_all(const WgradLayer& L) {
-  size_t n = 0;
   for (int i = 0; i < L.nparts; ++i) n += (wgrad_partial_floats(L.part[i]) + 63) / 64 * 64;
   return n;
 }
 
-// the passes' launches only: every pass writes its own slab region of `partial` (wgrad_layer_partial_floats_all floats),
+// the passes' launches only: every pass writes its own slab region of `partial` (wgrad_layer_partial_floats floats),
 // and its reduce is appended to `tb` for a later wgrad_reduce_batch_launch on the same stream
 int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                                 float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
@@ -773,21 +679,9 @@ int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void*
 
 int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                        float* dw, int CoutReal, int CinReal, int dtype, hipStream_t stream) {
-  WgradDst dst;
-  dst.n = 1;
-  dst.dw[0] = dw;
-  for (int i = 0; i < L.nparts; ++i) {
-    WgradParams w = L.part[i];
-    w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = partial;
-    if (int rc = wgrad_launch(w, dtype, stream)) return rc;
-    const int c_off = w.ci_base;
-    // real channels of this part: channel padding only ever sits at the end of the concatenation
-    const int creal = std::max(0, std::min(w.slab_cin, CinReal - c_off));
-    if (int rc = wgrad_reduce_launch_part(partial, w.splits, w.Cout, CoutReal, w.slab_cin, creal,
-                                          CinReal, c_off, w.KH, w.KW, w.cls, dst, stream))
-      return rc;
-  }
-  return 0;
+  WgradReduceBatch tb;
+  if (int rc = wgrad_layer_launch_deferred(L, dy, src0, src1, partial, dw, CoutReal, CinReal, dtype, tb, stream)) return rc;
+  return wgrad_reduce_batch_launch(tb, stream);
 }
 
 }  // namespace d3f

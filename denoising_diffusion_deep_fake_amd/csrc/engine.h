@@ -56,22 +56,13 @@ struct Unit {
   int wino_rows = 0;
   int C0Rows = 0, C1Rows = 0;
   ConvParams dgrad_lo{};
-  int wgroup = -1;      // weight-gradient launch group (index into UnetEngine::wgroups)
   ConvParams fwd{}, dgrad{};
-  WgradParams wg{};
   // weight gradient as WG_CLASS + WG_SKIP passes (conv_wgrad.hip): the decoder layers behind an up-sampling whose
   // gradient runs on the tap-parallel kernel -- 4/9 of the MACs on the up-sampled channels
   bool wclass = false;
   WgradLayer wl{};
-  size_t wslab_off = 0;  // this unit's own slab region (its reduce is deferred to the end of the gradient bucket)
+  size_t wslab_off = 0;  // this unit's own slab region
   int Cin() const { return C0 + C1; }
-};
-
-// Weight-gradient launch group: layers of identical shape inside one gradient bucket (the 3x3 stride-1
-// convolutions of a ResNet stage) whose weight gradients run as ONE launch once the LAST member's dY exists.
-struct WGroup {
-  std::vector<int> units;  // in backward order; the launch is issued behind units.back()
-  WgradParams wg{};        // planned for units.size() members
 };
 
 enum BwdKind { BW_HEAD, BW_UNIT, BW_SUM2X2, BW_POOL };
@@ -173,36 +164,25 @@ class UnetEngine {
   std::vector<int> grad_of;       // tensor id -> grad id or -1
   std::vector<bool> grad_init;    // plan-time: has a writer been emitted yet
   std::vector<BwdOp> bwd_ops;
-  std::vector<WGroup> wgroups;
   std::vector<int> fwd_order_;    // unit ids in execution order, -1 = max-pool
   // backward concurrency: weight gradients run on a side stream next to the data-gradient / BN chain.  Every unit
   // keeps its own dY (585 MB at bs 16, 256x256: nothing next to 288 GB), so the side stream never holds the main
-  // chain back and a group's launch can wait for its last member.
+  // chain back.
   mutable hipStream_t side_ = nullptr;
   mutable std::vector<hipEvent_t> ev_dy_;  // one per weight-gradient launch of a backward pass
   mutable hipEvent_t ev_join_ = nullptr;
   mutable hipEvent_t ev_seg_ = nullptr;   // "caller's stream has left the segment" (join == 0 calls)
   mutable bool side_dirty_ = false;       // work was put on the side stream that no stream has joined yet
-  // third stream: the decoder's skip-tensor data gradients.  They are consumed by the encoder stages, i.e. a whole
-  // decoder later, so they leave the dependent chain and fill the machine next to its BatchNorm kernels
   // weight packing off the critical path: the layouts of encoder.conv1 / layer1 / layer2 (5 % of the parameters) are
   // packed on the caller's stream, the rest on the side stream while those layers already run; the forward pass
   // waits for it in front of the first later layer
   int ensure_streams() const;
-  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr, ev_pack_mid_ = nullptr, ev_pack_d_ = nullptr;
+  mutable hipEvent_t ev_pack_in_ = nullptr, ev_pack_done_ = nullptr, ev_pack_mid_ = nullptr;
   mutable bool pack_pending_ = false, pack_mid_pending_ = false;
-  // opt-in (D3F_LATE_DGRAD_PACK=1): the data-gradient layouts as a FOURTH part behind the forward layouts -- nothing
-  // reads them before the backward pass, and next to the HBM-bound first kernels of the forward pass the packing's
-  // 300 MB of traffic doubles the stem's time (158 vs 71 us); measured slower overall, see pack_weights
-  mutable bool pack_d_pending_ = false;
   // Weight packing in three parts: encoder.conv1 on the caller's stream (the forward needs it at once), layer1-2 and
   // then everything else on the side stream, each behind its own event.
   int first_mid_unit_ = -1;   // first unit (index into `units`) of the second part (encoder.layer1)
   int first_late_unit_ = -1;  // first unit of the third part (encoder.layer3)
-  mutable hipStream_t aux_ = nullptr;
-  mutable hipEvent_t ev_aux_ = nullptr;
-  mutable std::vector<hipEvent_t> ev_auxdy_;
-  size_t splitk_aux_off = 0, splitk_aux_bytes = 0;
   // predict_u8 graph: private capture/launch stream + the pointers and constants the captured graph bakes in
   int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
   int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
@@ -230,8 +210,8 @@ class UnetEngine {
   size_t ws_top = 0;
   int t_x = -1, t_pool = -1, head = -1, conv1 = -1;
   size_t pool_idx_off = 0, stats_off = 0, bnpart_off = 0, dz_off = 0, dfull_off = 0,
-         wpart_off = 0, bsum_off = 0, splitk_off = 0;
-  size_t stats_bytes = 0, bnpart_bytes = 0, dy_bytes = 0, dz_bytes = 0, dfull_bytes = 0, wpart_bytes = 0, splitk_bytes = 0;
+         bsum_off = 0, splitk_off = 0;
+  size_t stats_bytes = 0, bnpart_bytes = 0, dy_bytes = 0, dz_bytes = 0, dfull_bytes = 0, splitk_bytes = 0;
 };
 
 int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,

@@ -151,8 +151,7 @@ int UnetEngine::add_unit(const std::string& conv_name, const std::string& bn_nam
     u.CinRows = (int)round_up(u.Cin(), 16);
     u.wd_off = alloc((size_t)u.CinRows * u.KpadD * wsize());
   }
-  static const bool no_upfold = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob: gather through the up-sampling
-  u.upfold = !no_upfold && upfold_applies(dtype, up0, k, stride, pad, u.C0, u.C1);
+  u.upfold = upfold_applies(dtype, up0, k, stride, pad, u.C0, u.C1);
   if (u.upfold) {
     u.C0Rows = (int)round_up(u.C0, 16);
     u.C1Rows = (int)round_up(u.C1, 16);
@@ -202,7 +201,7 @@ int UnetEngine::plan_unit(Unit& u) {
   if (dyb > dy_bytes) dy_bytes = dyb;
   if (!u.apply && u.bn && dyb > dz_bytes) dz_bytes = dyb;
 
-  WgradParams& g = u.wg;
+  WgradParams g;
   std::memset(&g, 0, sizeof(g));
   g.B = B; g.Hv = u.Hv; g.Wv = u.Wv; g.C0 = u.C0; g.C1 = u.C1;
   g.H0s = u.Hv >> u.up0; g.W0s = u.Wv >> u.up0; g.shift0 = u.up0;
@@ -210,21 +209,9 @@ int UnetEngine::plan_unit(Unit& u) {
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = (int)rows_full;
   g.cin_real = u.CinReal;
   g.flops = 2.0 * macs;
-  {
-    const WgradParams base = g;
-    if (int rc = wgrad_layer_plan(u.wl, base, dtype)) return rc;
-    u.wclass = u.wl.part[0].part != WG_WHOLE;
-    if (u.wclass) {
-      const size_t wb = wgrad_layer_partial_floats(u.wl) * sizeof(float);
-      if (wb > wpart_bytes) wpart_bytes = wb;
-    }
-    u.wslab_off = alloc(wgrad_layer_partial_floats_all(u.wl) * sizeof(float));
-  }
-  if (int rc = wgrad_plan(g, dtype)) return rc;  // single-layer plan; identical layers are re-planned as a group in build()
-  {
-    const size_t wb = wgrad_partial_floats(g) * sizeof(float);
-    if (wb > wpart_bytes) wpart_bytes = wb;
-  }
+  if (int rc = wgrad_layer_plan(u.wl, g, dtype)) return rc;
+  u.wclass = u.wl.part[0].part != WG_WHOLE;
+  u.wslab_off = alloc(wgrad_layer_partial_floats(u.wl) * sizeof(float));
   u.dy_off = alloc(dyb);
 
   if (u.need_dgrad && u.upfold) {
@@ -254,8 +241,7 @@ int UnetEngine::plan_unit(Unit& u) {
       d.mode = CONV_DGRAD;
       d.out_c0 = u.C1;
       if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
-      // its own split-K scratch: this launch runs on the auxiliary stream, concurrently with the main chain's
-      if (conv_splitk_floats(d) * sizeof(float) > splitk_aux_bytes) splitk_aux_bytes = conv_splitk_floats(d) * sizeof(float);
+      if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
       d.flops = 2.0 * macs * u.C1 / u.Cin();
     }
     bwd_flops += 2.0 * macs;
@@ -388,7 +374,6 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       if (u.upfold) {  // two launches: low-resolution source (dst0) and skip tensor (dst1), both written directly
         op.dst0 = grad_dst(u.in0, &op.acc0);
         if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
-        // backward() runs the skip gradients on its auxiliary stream and joins it on leaving bucket 0
         D3F_CHECK(u.segment == 0, "plan: unit %s: a folded up-sampling layer outside the decoder bucket", u.conv_name.c_str());
       } else if (u.up0) {
         op.dst0_is_full_scratch = true;
@@ -446,7 +431,8 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   // gradient also emits the (dbeta, dgamma) partial sums of the unit that consumes it -- when that unit is the very
   // next op (bnpart is one stream-ordered scratch).  The producer may accumulate (it sums first, then reduces the
   // final values); a consumer with a residual add takes its ReLU mask from its activation instead of from y.
-  if (getenv("D3F_NO_FUSED_BN_REDUCE") == nullptr) {
+  static const bool no_fused_reduce = getenv("D3F_NO_FUSED_BN_REDUCE") != nullptr;  // debugging knob: separate reduce launches
+  if (!no_fused_reduce) {
     auto writes = [&](const BwdOp& o, int gid) {
       if (o.kind == BW_UNIT || o.kind == BW_HEAD) {
         if (units[o.unit].need_dgrad && !o.dst0_is_full_scratch && o.dst0 == gid) return true;
@@ -455,7 +441,6 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       }
       return (o.kind == BW_SUM2X2 || o.kind == BW_POOL) && o.dst0 == gid;
     };
-    static const bool old_rule = getenv("D3F_FUSE_SINGLE_WRITER_ONLY") != nullptr;  // debugging knob: round-1 rule
     for (size_t j = 0; j + 1 < bwd_ops.size(); ++j) {
       BwdOp& pj = bwd_ops[j];
       if (!(pj.kind == BW_UNIT || pj.kind == BW_HEAD)) continue;
@@ -466,12 +451,8 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       if (ck.kind != BW_UNIT || ck.dA != pj.dst0) continue;
       bool last = true;  // no later writer, and (a dres write of op j itself happens BEFORE its data gradient)
       for (size_t k = j + 1; k < bwd_ops.size(); ++k) last = last && !writes(bwd_ops[k], pj.dst0);
-      int nw = 0;
-      for (const BwdOp& o : bwd_ops) nw += writes(o, pj.dst0) ? 1 : 0;
       const Unit& uc = units[ck.unit];
-      const bool residual = uc.res_tensor >= 0 || uc.res_unit >= 0;
       if (!last || !(uc.bn && ck.mask)) continue;
-      if (old_rule && (nw != 1 || pj.acc0 || residual)) continue;
       D3F_CHECK(pd.Cout == uc.Cout && pd.M == B * uc.Ho * uc.Wo && pd.out_c0 == pd.Cout,
                 "plan: fused BatchNorm reduce shape mismatch (%s -> %s)", up.conv_name.c_str(), uc.conv_name.c_str());
       pj.fuse_for_unit = ck.unit;
@@ -480,64 +461,13 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
     }
   }
 
-  // ---- weight-gradient launch groups: identical plain layers of one bucket, in backward order ----------------
-  {
-    static const bool no_groups = getenv("D3F_NO_WGRAD_GROUPS") != nullptr;  // debugging knob: one launch per layer
-    // A group launches behind its LAST member, so a big group near the end of the backward pass leaves its work
-    // with nothing to overlap: the cap shrinks towards the end of the pass -- per encoder stage (512, 256, 128, 64
-    // output channels = the order the backward pass visits them).  Tuning knobs: D3F_WGRAD_GROUP_CAPS="a,b,c,d",
-    // D3F_WGRAD_GROUP_MAX=n (a cap on all of them).
-    // Default since r02_ab/ac/ad: ONE launch per layer (caps 1,1,1,1).  A grouped launch (2880 workgroups of ~140 us
-    // for layer4) fills every wave slot of the chip, and stream priority only decides who gets a FREE slot: the
-    // chain's next 5 us BatchNorm kernel then waited 80-140 us for one (profiles/r02_aa_step_launches.txt).  With the
-    // BatchNorm finalize launches gone from the chain, per-layer launches are 1.3 % faster per step than 5,4,2,1
-    // although they write more slabs.
-    int caps[4] = {1, 1, 1, 1};
-    if (const char* gc = getenv("D3F_WGRAD_GROUP_CAPS")) sscanf(gc, "%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3]);
-    int group_max = WG_MAXG;
-    if (const char* gm = getenv("D3F_WGRAD_GROUP_MAX")) group_max = std::max(1, std::min(WG_MAXG, atoi(gm)));
-    auto cap_of = [&](const Unit& u) {
-      const int c = u.Cout >= 512 ? caps[0] : u.Cout >= 256 ? caps[1] : u.Cout >= 128 ? caps[2] : caps[3];
-      return std::max(1, std::min(group_max, c));
-    };
-    auto same = [](const Unit& a, const Unit& b) {
-      return a.segment == b.segment && a.Hv == b.Hv && a.Wv == b.Wv && a.C0 == b.C0 && a.C1 == 0 && b.C1 == 0 &&
-             a.up0 == 0 && b.up0 == 0 && a.CoutD == b.CoutD && a.Cout == b.Cout && a.CinReal == b.CinReal &&
-             a.KH == b.KH && a.stride == b.stride && a.pad == b.pad && a.wg.patch == 0 && b.wg.patch == 0;
-    };
-    for (const BwdOp& op : bwd_ops) {
-      if (op.kind != BW_UNIT && op.kind != BW_HEAD) continue;
-      Unit& u = units[op.unit];
-      int found = -1;
-      if (!no_groups)
-        for (size_t gi = 0; gi < wgroups.size() && found < 0; ++gi)
-          if ((int)wgroups[gi].units.size() < cap_of(u) && same(units[wgroups[gi].units[0]], u)) found = (int)gi;
-      if (found < 0) {
-        wgroups.emplace_back();
-        found = (int)wgroups.size() - 1;
-      }
-      wgroups[found].units.push_back(op.unit);
-      u.wgroup = found;
-    }
-    for (WGroup& g : wgroups) {
-      g.wg = units[g.units[0]].wg;
-      const int n = (int)g.units.size();
-      if (n > 1)
-        if (int rc = wgrad_plan(g.wg, dtype, n)) return rc;
-      const size_t wb = wgrad_partial_floats(g.wg) * n * sizeof(float);
-      if (wb > wpart_bytes) wpart_bytes = wb;
-    }
-  }
-
   // ---- scratch ------------------------------------------------------------------------
   stats_off = alloc(stats_bytes);
   bnpart_off = alloc(bnpart_bytes);
   dz_off = alloc(dz_bytes);
   dfull_off = alloc(dfull_bytes);
-  wpart_off = alloc(wpart_bytes);
   bsum_off = alloc(channel_sum_partial_floats(B, classes) * sizeof(float));
   splitk_off = alloc(splitk_bytes);
-  splitk_aux_off = alloc(splitk_aux_bytes);
   head_nchw_off = alloc((size_t)B * classes * H * W * sizeof(float));  // predict_u8: head output before K16 post
   workspace_bytes = ws_top;
 
@@ -573,21 +503,17 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
 int UnetEngine::ensure_streams() const {
   if (side_ != nullptr) return 0;
   // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
-  // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured;
-  // D3F_SIDE_PRIORITY=0 turns it off).  A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
+  // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured).
+  // A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
   // left to the caller's stream) was tried and halves the throughput on this platform.
   int least = 0, greatest = 0;
   D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  static const bool no_prio = getenv("D3F_SIDE_PRIORITY") != nullptr && atoi(getenv("D3F_SIDE_PRIORITY")) == 0;
-  D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, no_prio ? 0 : least));
+  D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, least));
   D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_seg_, hipEventDisableTiming));
-  D3F_HIP(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
-  D3F_HIP(hipEventCreateWithFlags(&ev_aux_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_done_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_mid_, hipEventDisableTiming));
-  D3F_HIP(hipEventCreateWithFlags(&ev_pack_d_, hipEventDisableTiming));
   return 0;
 }
 
@@ -597,28 +523,21 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
   static const bool sync_pack = getenv("D3F_NO_ASYNC_PACK") != nullptr;  // debugging knob: everything on the caller's stream
   const bool async = !sync_pack && first_late_unit_ > 0;
   char* ws = reinterpret_cast<char*>(ws_);
-  static const bool no_mid = getenv("D3F_NO_PACK_MID") != nullptr;  // debugging knob: two parts (layer1-2 with conv1)
-  const int mid = (async && !no_mid) ? first_mid_unit_ : -1;
+  const int mid = async ? first_mid_unit_ : -1;
   // parts: 0 = the first layers (caller's stream: encoder.conv1, or everything before layer3 without a middle part),
   // 1 = layer1-2 (side stream, own event; empty without a middle part), 2 = the rest (side stream)
   auto part_of = [&](int ui) { return ui >= first_late_unit_ ? 2 : (mid > 0 && ui >= mid) ? 1 : 0; };
-  // part 3 (tuning knob D3F_LATE_DGRAD_PACK=1, off): every data-gradient layout in its own pass behind the forward
-  // layouts.  Measured SLOWER (r03: 8.17 -> 8.27 ms, forward conv class 2.55 -> 2.63): the stem gets its 87 us back, but
-  // the extra pass then runs next to layer1-2's MFMA-bound convolutions and costs them more
-  static const bool want_late_d = getenv("D3F_LATE_DGRAD_PACK") != nullptr;
-  const bool late_d = async && want_late_d;
-  for (int part = 0; part < 4; ++part) {
+  // (the data-gradient layouts in a separate, later pass were measured slower: profiles/README.md round 3)
+  for (int part = 0; part < 3; ++part) {
     if (part == 1 && mid <= 0) continue;
-    if (part == 3 && !late_d) continue;
     PackTable t;
     t.n = 0;
     uint32_t blocks = 0;
     for (int ui = 0; ui < (int)units.size(); ++ui) {
       const Unit& u = units[ui];
-      if (part < 3 && first_late_unit_ > 0 && part_of(ui) != part) continue;
-      if (part < 3 && first_late_unit_ <= 0 && part != 0) continue;
+      if (first_late_unit_ > 0 && part_of(ui) != part) continue;
+      if (first_late_unit_ <= 0 && part != 0) continue;
       if (u.upfold) continue;  // packed by pack_up_launch below (none of the plain layouts is read for these layers)
-      if (part == 3 && !u.need_dgrad) continue;
       PackEntry& e = t.e[t.n++];
       const int CoutD = (int)round_up(u.Cout, ve);
       const long nf = (long)u.CoutPad * u.Kpad, nd = u.need_dgrad ? (long)u.CinRows * u.KpadD : 0;
@@ -635,7 +554,6 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       e.taps = (uint16_t)(u.KH * u.KW); e.CoutPad = (uint16_t)u.CoutPad; e.Kpad = (uint16_t)u.Kpad;
       e.CinRows = (uint16_t)u.CinRows; e.CoutD = (uint16_t)CoutD; e.KpadD = (uint16_t)u.KpadD;
       e.has_d = u.need_dgrad ? 1 : 0;
-      e.which = part == 3 ? 2 : (late_d ? 1 : 3);
       e.conv_stride = (u.need_dgrad && u.dgrad.par) ? 2 : 1;
       const int taps = u.KH * u.KW;
       D3F_CHECK(taps <= PACK_LDS_ROW, "pack_weights: %d taps exceed the tile", taps);
@@ -665,8 +583,8 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     }
     if (t.n > 0)
       if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
-    if (part < 3)  // transformed filters of the Winograd layers of this part, behind its plain layouts
-      for (int ui = 0; ui < (int)units.size(); ++ui) {
+    // transformed filters of the Winograd layers of this part, behind its plain layouts
+    for (int ui = 0; ui < (int)units.size(); ++ui) {
         const Unit& u = units[ui];
         if (!u.wino) continue;
         if (first_late_unit_ > 0 ? part_of(ui) != part : part != 0) continue;
@@ -688,10 +606,6 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
     if (part == 2 && async) {
       D3F_HIP(hipEventRecord(ev_pack_done_, side_));
       pack_pending_ = true;
-    }
-    if (part == 3) {
-      D3F_HIP(hipEventRecord(ev_pack_d_, side_));
-      pack_d_pending_ = true;
     }
   }
   return 0;
@@ -895,7 +809,7 @@ int UnetEngine::train_step(const StepArgs& a, void* ws_, int use_graph, hipStrea
     D3F_HIP(hipStreamBeginCapture(gstream_, hipStreamCaptureModeThreadLocal));
     const int rc = train_step_launches(a, ws_, gstream_);
     const hipError_t e = hipStreamEndCapture(gstream_, &graph);
-    pack_pending_ = pack_mid_pending_ = pack_d_pending_ = false;  // (consumed inside the capture)
+    pack_pending_ = pack_mid_pending_ = false;  // (consumed inside the capture)
     side_dirty_ = false;
     if (rc != 0) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -922,10 +836,6 @@ int UnetEngine::wait_for_packed_weights(hipStream_t s) const {
   if (pack_pending_) {
     D3F_HIP(hipStreamWaitEvent(s, ev_pack_done_, 0));
     pack_pending_ = false;
-  }
-  if (pack_d_pending_) {
-    D3F_HIP(hipStreamWaitEvent(s, ev_pack_d_, 0));
-    pack_d_pending_ = false;
   }
   return 0;
 }
@@ -981,24 +891,19 @@ UnetEngine::~UnetEngine() {
     if (e) (void)hipEventDestroy(e);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (ev_seg_) (void)hipEventDestroy(ev_seg_);
-  for (hipEvent_t e : ev_auxdy_)
-    if (e) (void)hipEventDestroy(e);
-  if (ev_aux_) (void)hipEventDestroy(ev_aux_);
   if (ev_pack_in_) (void)hipEventDestroy(ev_pack_in_);
   if (ev_pack_done_) (void)hipEventDestroy(ev_pack_done_);
   if (ev_pack_mid_) (void)hipEventDestroy(ev_pack_mid_);
-  if (ev_pack_d_) (void)hipEventDestroy(ev_pack_d_);
-  if (aux_) (void)hipStreamDestroy(aux_);
   if (side_) (void)hipStreamDestroy(side_);
 }
 
 // Backward of segments [seg_begin, seg_end).  Per unit: BN backward (writes the unit's dY) -> {weight gradient,
 // data gradient}.  The two gradients are independent, and the following unit's BN-backward kernels are
 // HBM-bound while the weight gradient is MFMA-bound, so the weight gradients (+ their slab reduces) run on
-// a side stream: main records "dY ready", side waits for it.  Layers of identical shape share ONE weight-gradient
-// launch (WGroup), issued behind the group's last member; every unit owns its dY, so nothing on the main chain
-// ever waits for the side stream, which is joined before returning: after the call every gradient of the
-// segments is final on the caller's stream.
+// a side stream: main records "dY ready", side waits for it.  One weight-gradient launch (+ slab reduce) per layer
+// (grouped launches of identical layers fill every wave slot in front of the chain's next kernels: measured slower,
+// profiles/README.md round 2); every unit owns its dY, so nothing on the main chain ever waits for the side stream,
+// which is joined before returning: after the call every gradient of the segments is final on the caller's stream.
 static bool serial_backward() {
   static const bool serial = getenv("D3F_SERIAL_BACKWARD") != nullptr;  // debugging knob: no side stream
   return serial;
@@ -1035,40 +940,19 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
 #endif
   if (!serial)
     if (int rc = ensure_streams()) return rc;
-  if (pack_d_pending_) {  // the data-gradient layouts come from the side stream (pack_weights, part 3)
-    D3F_HIP(hipStreamWaitEvent(s, ev_pack_d_, 0));
-    pack_d_pending_ = false;
-  }
-  // opt-in (D3F_AUX_STREAM=1): measured 1 % SLOWER than keeping the skip gradients on the caller's stream -- a third
-  // stream of MFMA-bound work slows the dependent chain's own kernels more than the moved launches save
-  static const bool want_aux = getenv("D3F_AUX_STREAM") != nullptr && atoi(getenv("D3F_AUX_STREAM")) != 0;
-  const bool use_aux = !serial && want_aux;
-  size_t next_aux = 0;
-  bool aux_used = false, aux_joined = false;
   hipStream_t ws_stream = serial ? s : side_;
-  float* wpart = reinterpret_cast<float*>(ws + wpart_off);
   size_t next_event = 0;
   bool side_used = false;
   // Weight-gradient launches waiting for their "dY ready" event: one event for every `defer` launches (an event
-  // record costs the chain a few us of dispatch latency, a deferred launch starts later).  Measured (r02_ap/aq,
-  // D3F_WGRAD_DEFER=1/2/3/4): 3 gives the shortest data-gradient launches (class 3.80 -> 3.64 ms per step) at an
-  // equal or slightly shorter step; 2 and 4 are 0.5-1 % slower.  Pending launches never cross a gradient-bucket
-  // (segment) boundary.
-  static const int defer = getenv("D3F_WGRAD_DEFER") ? std::max(1, atoi(getenv("D3F_WGRAD_DEFER"))) : 3;
+  // record costs the chain a few us of dispatch latency, a deferred launch starts later).  Measured (r02_ap/aq, 1 / 2 / 3 /
+  // 4 launches per event): 3 gives the shortest data-gradient launches (class 3.80 -> 3.64 ms per step) at an equal or
+  // slightly shorter step; 2 and 4 are 0.5-1 % slower.  Pending launches never cross a gradient-bucket (segment) boundary.
+  constexpr int defer = 3;
   std::vector<int> pending;
   int pending_segment = -1;
-  // Slab reduces: one launch right behind every layer (every unit owns its slab region).  D3F_WGRAD_BATCH=1 (tuning
-  // knob) defers them into one launch per gradient bucket: 47 -> 4-6 launches, same sums, but measured equal or slightly
-  // SLOWER per step (r03: 8.36 vs 8.38 ms fp32, 4.53 vs 4.62 bf16, 3.77 vs 3.86 at 128x128) -- the big launches at the
+  // Slab reduces: one launch right behind every layer (every unit owns its slab region).  One launch per gradient
+  // bucket (47 -> 4-6 launches, same sums) was measured equal or slightly SLOWER per step (r03): the big launches at the
   // bucket ends delay the buckets' "gradients final" point and the stream's tail more than the 40 launches cost.
-  static const bool no_batch = getenv("D3F_WGRAD_BATCH") == nullptr;
-  WgradReduceBatch red;
-  auto flush_reduces = [&]() -> int {
-    if (red.n == 0) return 0;
-    const int rc = skip_r ? 0 : wgrad_reduce_batch_launch(red, ws_stream);
-    red = WgradReduceBatch();
-    return rc;
-  };
   auto flush_pending = [&]() -> int {
     if (pending.empty()) return 0;
     if (!serial) {
@@ -1084,36 +968,13 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
     for (int ui : pending) {
       const Unit& u = units[ui];
-      const WGroup& grp = wgroups[u.wgroup];
-      if (grp.units.size() == 1) {  // (grouped launches -- a tuning knob -- keep the shared scratch and their own reduce)
-        if (red.n + u.wl.nparts > WG_BATCH)
-          if (int rc = flush_reduces()) return rc;
-        if (int rc = wgrad_layer_launch_deferred(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr,
-                                                 reinterpret_cast<float*>(ws + u.wslab_off), grads + u.w_off, u.Cout,
-                                                 u.CinReal, cdtype, red, ws_stream))
-          return rc;
-        if (no_batch)
-          if (int rc = flush_reduces()) return rc;
-        continue;
-      }
-      WgradParams g = grp.wg;
-      WgradGroup gp;
-      WgradDst gd;
-      gp.n = gd.n = (int)grp.units.size();
-      for (int i = 0; i < gp.n; ++i) {
-        const Unit& m = units[grp.units[i]];
-        gp.dy[i] = ws + m.dy_off;
-        gp.src0[i] = T(m.in0);
-        gd.dw[i] = grads + m.w_off;
-      }
-      g.dy = gp.dy[0];
-      g.src0 = gp.src0[0];
-      g.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;  // two-source layers are never grouped
-      g.partial = wpart;
-      if (int rc = wgrad_launch_group(g, gp, cdtype, ws_stream)) return rc;
+      WgradReduceBatch red;
+      if (int rc = wgrad_layer_launch_deferred(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr,
+                                               reinterpret_cast<float*>(ws + u.wslab_off), grads + u.w_off, u.Cout,
+                                               u.CinReal, cdtype, red, ws_stream))
+        return rc;
       if (!skip_r)
-        if (int rc = wgrad_reduce_launch(wpart, g.splits, u.CoutD, u.Cout, u.Cin(), u.CinReal, u.KH, u.KW, gd, ws_stream))
-          return rc;
+        if (int rc = wgrad_reduce_batch_launch(red, ws_stream)) return rc;
     }
     pending.clear();
     return 0;
@@ -1121,15 +982,8 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   for (const BwdOp& op : bwd_ops) {
     if (op.segment < seg_begin || op.segment >= seg_end) continue;
     if (op.segment != pending_segment) {
-      if (int rc = flush_pending()) return rc;
-      if (int rc = flush_reduces()) return rc;  // the bucket's gradients are final behind this launch
+      if (int rc = flush_pending()) return rc;  // the bucket's gradients are final behind these launches
       pending_segment = op.segment;
-    }
-    if (aux_used && !aux_joined && op.segment != 0) {
-      // leaving the decoder bucket: the encoder stages read and accumulate into the skip tensors' gradients
-      D3F_HIP(hipEventRecord(ev_aux_, aux_));
-      D3F_HIP(hipStreamWaitEvent(s, ev_aux_, 0));
-      aux_joined = true;
     }
     if (op.kind == BW_SUM2X2) {
       if (int rc = sum2x2_launch(dtype, ws + dfull_off, G(op.dst0), B, op.Hl, op.Wl, op.C, s)) return rc;
@@ -1159,8 +1013,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       // ReLU mask: layers without a residual recompute it from y (identical to a > 0: the forward apply used the
       // same fp32 y*scale + shift on the same stored y, and rounding a positive fp32 value to bf16 never gives
       // zero); residual layers read the saved activation
-      static const bool bf16_mask_from_a = getenv("D3F_BF16_MASK_FROM_A") != nullptr;  // debugging knob
-      const bool from_y = op.mask && (dtype == D3F_F32 || !bf16_mask_from_a) && u.res_tensor < 0 && u.res_unit < 0;
+      const bool from_y = op.mask && u.res_tensor < 0 && u.res_unit < 0;
       const void* amask = (op.mask && !from_y) ? T(u.a) : nullptr;
       const float* msc = from_y ? coef_ptr(ws, u, 2) : nullptr;
       const float* msf = from_y ? coef_ptr(ws, u, 3) : nullptr;
@@ -1205,9 +1058,8 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
           return rc;
       }
     }
-    // weight gradient of the unit's launch group (side stream), once the group's last dY exists
-    const WGroup& grp = wgroups[u.wgroup];
-    if (grp.units.back() == op.unit && !skip_w) {
+    // weight gradient (side stream), once the unit's dY exists
+    if (!skip_w) {
       pending.push_back(op.unit);
       if ((int)pending.size() >= defer)
         if (int rc = flush_pending()) return rc;
@@ -1232,28 +1084,15 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       }
       if (int rc = conv_igemm_launch(l, cdtype, s)) return rc;
       if (op.dst1 >= 0) {
-        // the skip tensor's gradient is not read before the encoder stages: auxiliary stream, joined at the end of
-        // this call (the decoder is one gradient bucket, its skip gradients are consumed by later ones)
-        hipStream_t ds = s;
-        if (use_aux) {
-          if (next_aux == ev_auxdy_.size()) {
-            hipEvent_t e = nullptr;
-            D3F_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ev_auxdy_.push_back(e);
-          }
-          D3F_HIP(hipEventRecord(ev_auxdy_[next_aux], s));  // dY (and, for an accumulate, every earlier writer) done
-          D3F_HIP(hipStreamWaitEvent(aux_, ev_auxdy_[next_aux], 0));
-          ++next_aux;
-          aux_used = true;
-          ds = aux_;
-        }
+        // the skip tensor's gradient (not read before the encoder stages; a third stream for these launches was measured
+        // 1 % slower -- MFMA-bound work next to the chain's own kernels -- profiles/README.md round 2)
         ConvParams d = u.dgrad;
         d.src0 = dy;
         d.w = ws + u.wds_off;
         d.out0 = G(op.dst1);
         d.acc0 = op.acc1 ? 1 : 0;
-        d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + (use_aux ? splitk_aux_off : splitk_off)) : nullptr;
-        if (int rc = conv_igemm_launch(d, cdtype, ds)) return rc;
+        d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+        if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
       }
     } else if (u.need_dgrad && !skip_d) {
       ConvParams d = u.dgrad;
@@ -1282,7 +1121,6 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     }
   }
   if (int rc = flush_pending()) return rc;
-  if (int rc = flush_reduces()) return rc;
   if (!serial && side_used) side_dirty_ = true;
   if (!serial && !join) {
     // data-parallel caller: the caller's stream (the critical path) is NOT held back.  The side stream waits for the
@@ -1293,10 +1131,6 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     side_dirty_ = true;
   } else if (!serial) {  // join: every gradient of these segments is final on the caller's stream
     if (int rc = backward_join(s)) return rc;
-  }
-  if (aux_used && !aux_joined) {
-    D3F_HIP(hipEventRecord(ev_aux_, aux_));
-    D3F_HIP(hipStreamWaitEvent(s, ev_aux_, 0));
   }
   return 0;
 }

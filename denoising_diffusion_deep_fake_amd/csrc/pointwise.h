@@ -108,7 +108,7 @@ struct PackEntry {
   uint32_t block0;              // first block of this layer; blocks are (filter tile, channel tile)
   uint16_t Cout, CinReal, Cin, taps, CoutPad, Kpad, CinRows, CoutD, KpadD, has_d, CT, ctiles;
   uint16_t conv_stride;         // 2: data-gradient taps stored parity class by class (dgrad_tap_slot_to_flipped)
-  uint16_t which;               // layouts this launch writes: bit 0 forward, bit 1 data gradient
+  uint16_t pad0;
   uint16_t taps_shr, ct_log2;   // index arithmetic without divisions: q / taps = umulhi(q, taps_mul) >> taps_shr
   uint32_t taps_mul;            // (fast_div_setup, common.h; 0 = one tap), CT = 1 << ct_log2
 };

@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   __syncthreads();
   // ---- forward layout wf[n][tap*Cin + c] ----
-  if (e.which & 1)
+  if (true)
   for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
     const int cl = i & (CT - 1), q = i >> lgct;
     const int nl = fast_div(q, tmul, tshr), tap = q - nl * taps;
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     if (n < CoutPad && c < Cin)
       pack_store<T, X3>(wf, (long)(unsigned)(n * Kpad + tap * Cin + c), (long)CoutPad * Kpad, tile[nl * stride + cl * taps + tap]);
   }
-  if (ct == 0 && (e.which & 1)) {  // zero tail of each row: k in [taps*Cin, Kpad)
+  if (ct == 0) {  // zero tail of each row: k in [taps*Cin, Kpad)
     const int k0 = taps * Cin, tail = Kpad - k0;
     for (int i = threadIdx.x; i < PACK_NT * tail; i += 256) {
       const int n = n0 + i / tail;
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
   }
   // ---- data-gradient layout wd[c][tapf*CoutD + n], taps flipped ----
-  if (e.has_d && (e.which & 2)) {
+  if (e.has_d) {
     for (int i = threadIdx.x; i < PACK_NT * run; i += 256) {
       const int nl = i & (PACK_NT - 1), q = i / PACK_NT;
       const int cl = fast_div(q, tmul, tshr), slot = q - cl * taps;

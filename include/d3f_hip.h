@@ -38,7 +38,7 @@ extern "C" {
 
 int d3f_version(void);
 const char* d3f_last_error(void);
-/* First 16 hex digits of the sha256 over the sources this library was built from (csrc/*.hip, csrc/*.h, this header; the
+/* First 16 hex digits of the sha256 over the sources this library was built from (the .hip and .h files of csrc/ and this header; the
  * Makefile bakes it in).  The Python binding refuses a library whose digest differs from the sources next to it
  * (_lib.lib(); D3F_LIB=<path> loads a variant build on purpose and skips the check); bench.py prints it in `config`. */
 const char* d3f_source_digest(void);
