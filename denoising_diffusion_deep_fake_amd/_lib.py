@@ -71,6 +71,11 @@ PROTOTYPES = {
     "d3f_conv_workspace_bytes": (_sz, [_i, _desc, _i]),
     "d3f_conv_stats_floats": (_sz, [_i, _desc, _i, C.POINTER(_i)]),
     "d3f_conv_forward": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p, _p]),
+    "d3f_conv_winograd_applies": (_i, [_i, _desc]),
+    "d3f_conv_winograd_filter_bytes": (_sz, [_desc]),
+    "d3f_conv_winograd_stats_floats": (_sz, [_desc, C.POINTER(_i)]),
+    "d3f_conv_winograd_pack": (_i, [_desc, _p, _p, _p]),
+    "d3f_conv_winograd_forward": (_i, [_desc, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "d3f_conv_backward_data": (_i, [_i, _desc, _p, _p, _p, _p, _i, _i, _p, _p]),
     "d3f_conv_backward_weight_workspace_bytes": (_sz, [_i, _desc]),
     "d3f_conv_backward_weight": (_i, [_i, _desc, _p, _p, _p, _p, _p, _p]),

@@ -399,6 +399,55 @@ int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const 
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   return conv_igemm_launch(p, dtype, (hipStream_t)stream);
 }
+// ---- Winograd F(2x2, 3x3) form of a stride-1 3x3 fp32 layer on its own (conv_winograd.hip) ----
+static int wino_params(const d3f_conv_desc* d, ConvParams& p) {
+  if (int rc = fwd_params(D3F_F32, d, p, false)) return rc;
+  D3F_CHECK(conv_winograd_fits(p, D3F_F32),
+            "conv_winograd: needs 3x3 / stride 1 / pad 1, one source, H and W multiples of 16, channels a multiple of 16, "
+            "filters a multiple of 64 (got %dx%d k%d s%d p%d C0=%d C1=%d up=%d Cout=%d)",
+            d->H, d->W, d->KH, d->stride, d->pad, d->C0, d->C1, d->upsample0, d->Cout);
+  return 0;
+}
+int d3f_conv_winograd_applies(int dtype, const d3f_conv_desc* d) {
+  ConvParams p;
+  if (d == nullptr || desc_check(dtype, d) != 0 || fwd_params(dtype, d, p, false) != 0) return 0;
+  return conv_winograd_applies(p, dtype) ? 1 : 0;
+}
+size_t d3f_conv_winograd_filter_bytes(const d3f_conv_desc* d) {
+  ConvParams p;
+  return (d == nullptr || desc_check(D3F_F32, d) != 0 || fwd_params(D3F_F32, d, p, false) != 0 || !conv_winograd_fits(p, D3F_F32))
+             ? 0 : conv_winograd_filter_floats(p) * sizeof(float);
+}
+size_t d3f_conv_winograd_stats_floats(const d3f_conv_desc* d, int* tiles) {
+  ConvParams p;
+  if (d == nullptr || desc_check(D3F_F32, d) != 0 || fwd_params(D3F_F32, d, p, false) != 0 || !conv_winograd_fits(p, D3F_F32))
+    return 0;
+  const int rows = conv_winograd_stat_rows(p);
+  if (tiles) *tiles = rows;
+  return (size_t)rows * p.CoutPad * 2;
+}
+int d3f_conv_winograd_pack(const d3f_conv_desc* d, const float* w, void* u, void* stream) {
+  ConvParams p;
+  if (int rc = wino_params(d, p)) return rc;
+  D3F_CHECK(w && u && d->CinReal == d->C0, "conv_winograd_pack: null argument or padded input channels");
+  return conv_winograd_pack_launch(w, reinterpret_cast<float*>(u), d->Cout, d->C0, (hipStream_t)stream);
+}
+int d3f_conv_winograd_forward(const d3f_conv_desc* d, const void* src0, const void* u, void* y, float* stats,
+                              const float* scale, const float* shift, const void* residual, int relu, void* stream) {
+  ConvParams p;
+  if (int rc = wino_params(d, p)) return rc;
+  if (d->B == 0) return 0;
+  D3F_CHECK(src0 && u && y && ((scale == nullptr) == (shift == nullptr)), "conv_winograd_forward: null argument");
+  D3F_CHECK(scale != nullptr || (residual == nullptr && relu == 0),
+            "conv_winograd_forward: residual / ReLU belong to the eval epilogue (scale and shift)");
+  p.src0 = src0; p.w = u; p.out0 = y;
+  if (scale != nullptr) {
+    p.mode = CONV_EVAL_FUSED; p.scale = scale; p.shift = shift; p.res = residual; p.relu = relu ? 1 : 0;
+  } else {
+    p.mode = CONV_RAW_STATS; p.stats = stats; p.stat_rows = conv_winograd_stat_rows(p);
+  }
+  return conv_winograd_launch(p, (hipStream_t)stream);
+}
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
                            void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream) {
   ConvParams p;

@@ -221,7 +221,8 @@ size_t conv_splitk_floats(const ConvParams& p);
 int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream);
 // conv_patch.hip: LDS-patch form of the full-resolution 16-channel 3x3 layers (chosen inside conv_igemm_plan)
 // conv_winograd.hip: Winograd F(2x2, 3x3) forward of the wide-enough stride-1 3x3 layers in train mode (fp32)
-bool conv_winograd_applies(const ConvParams& p, int dtype);
+bool conv_winograd_fits(const ConvParams& p, int dtype);     // shapes the kernel can run
+bool conv_winograd_applies(const ConvParams& p, int dtype);  // shapes the plan takes it for (>= 256 workgroups)
 int conv_winograd_stat_rows(const ConvParams& p);           // one statistics row per workgroup
 size_t conv_winograd_filter_floats(const ConvParams& p);    // U[16][Cin / 16][Cout][16]
 int conv_winograd_pack_launch(const float* w /*[Cout][Cin][3][3]*/, float* u, int Cout, int Cin, hipStream_t stream);

@@ -33,19 +33,25 @@ typedef float wf32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int vsw(int row, int ch) { return ch ^ ((row >> 2) & 3); }
 }  // namespace
 
-bool conv_winograd_applies(const ConvParams& p, int dtype) {
-  static const bool off = getenv("D3F_NO_WINOGRAD") != nullptr;  // debugging knob: the implicit GEMM instead
-  if (off || dtype != D3F_F32) return false;
+// the shapes the kernel can run at all (the op-level entry d3f_conv_winograd_forward takes any of them)
+bool conv_winograd_fits(const ConvParams& p, int dtype) {
+  if (dtype != D3F_F32) return false;
   if (p.mode != CONV_RAW_STATS || p.par != 0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 ||
       p.shift0 != 0 || p.zi != 0 || p.Ho != p.Hv || p.Wo != p.Wv || (p.Ho % 16) != 0 || (p.Wo % 16) != 0 ||
       (p.C0 % WCK) != 0 || (p.Cout % 64) != 0 || p.CoutPad < p.Cout)
     return false;
   // 32-bit byte offsets behind buffer descriptors whose out-of-bounds marker is 2^31 (as in wgrad_plan)
   if ((size_t)p.B * p.Hv * p.Wv * p.C0 * 4 >= (1ull << 31) || (size_t)16 * p.C0 * p.Cout * 4 >= (1ull << 31)) return false;
+  return (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64) <= 65535L * 4;
+}
+// the plan's selection rule: the shapes where it beats the implicit GEMM
+bool conv_winograd_applies(const ConvParams& p, int dtype) {
+  static const bool off = getenv("D3F_NO_WINOGRAD") != nullptr;  // debugging knob: the implicit GEMM instead
+  if (off || !conv_winograd_fits(p, dtype)) return false;
   const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64);
   // one workgroup per CU or more, and few enough chunks that the fixed cost per workgroup is what the tile form pays for
   // (128 channels on 128 workgroups: 44.9 us against the implicit GEMM's 45)
-  return wgs >= 256 && wgs <= 65535L * 4;
+  return wgs >= 256;
 }
 int conv_winograd_stat_rows(const ConvParams& p) { return p.B * (p.Ho / 16) * (p.Wo / 16); }
 size_t conv_winograd_filter_floats(const ConvParams& p) { return (size_t)16 * p.C0 * p.Cout; }

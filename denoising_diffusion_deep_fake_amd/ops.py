@@ -78,6 +78,34 @@ def conv_forward(d, src0, src1, wf, dtype=F32, want_stats=True, splitk=False):
     return y, stats, tiles.value
 
 
+def conv_winograd_applies(d, dtype=F32):
+    """does the whole-network plan run this layer's forward as Winograd F(2x2, 3x3) (conv_winograd.hip)?"""
+    return bool(_lib.lib().d3f_conv_winograd_applies(dtype, C.byref(d)))
+
+
+def conv_winograd_pack(d, w):
+    L = _lib.lib()
+    n = L.d3f_conv_winograd_filter_bytes(C.byref(d))
+    if n == 0:
+        raise _lib.D3FError("conv_winograd_pack: the layer does not fit the Winograd kernel")
+    u = torch.empty(n, dtype=torch.uint8, device=_dev(w))
+    check(L.d3f_conv_winograd_pack(C.byref(d), ptr(w.contiguous().float()), ptr(u), stream_ptr()))
+    return u
+
+
+def conv_winograd_forward(d, src0, u, want_stats=True, scale=None, shift=None, residual=None, relu=False):
+    """fp32 Winograd forward on its own.  scale / shift given: the eval epilogue relu?(y * scale + shift + residual?);
+    else the raw conv output and one (sum, sumsq) statistics row per workgroup -> (y, stats, tiles)."""
+    L = _lib.lib()
+    y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=torch.float32, device=_dev(src0))
+    tiles = C.c_int()
+    n = L.d3f_conv_winograd_stats_floats(C.byref(d), C.byref(tiles))
+    stats = torch.zeros(n, dtype=torch.float32, device=y.device) if (want_stats and scale is None) else None
+    check(L.d3f_conv_winograd_forward(C.byref(d), ptr(src0), ptr(u), ptr(y), ptr(stats), ptr(scale), ptr(shift),
+                                      ptr(residual), int(relu), stream_ptr()))
+    return y, stats, tiles.value
+
+
 def conv_upsample_folded(d, dtype=F32):
     """does this conv(cat(upsample2x(src0), src1)) run with the up-sampling folded into pre-summed weights?"""
     return bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))

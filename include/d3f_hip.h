@@ -191,6 +191,20 @@ size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which);
 size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int with_workspace, int* tiles);
 int d3f_conv_forward(int dtype, const d3f_conv_desc* d, const void* src0, const void* src1,
                      const void* w_fwd, void* y, float* stats, void* workspace, void* stream);
+/* The Winograd F(2x2, 3x3) form of the same convolution for fp32 layers with a 3x3 / stride 1 / pad 1 kernel, one
+ * source, H and W multiples of 16, C0 a multiple of 16 and Cout a multiple of 64 (any other shape: D3F_EINVAL) -- the
+ * conv2d of torchvision's BasicBlock under smp.Unet(resnet34), d3f/train_denoiser/lit_module.py:46-52, :117.  The
+ * whole-network plan takes it where d3f_conv_winograd_applies() == 1 (at least 256 workgroups of 16x16 pixels x 64
+ * filters); this entry runs it on any shape it fits.  u: filters transformed by d3f_conv_winograd_pack from the torch
+ * weight [Cout][C0][3][3] (d3f_conv_winograd_filter_bytes bytes).  scale == NULL: y = conv(src0), stats (optional) =
+ * one (sum, sumsq) row per workgroup, d3f_conv_winograd_stats_floats() floats for d3f_bn_finalize.  scale != NULL:
+ * the eval epilogue y = relu?(conv(src0) * scale[c] + shift[c] + residual?) of the BatchNorm-folded forward. */
+int d3f_conv_winograd_applies(int dtype, const d3f_conv_desc* d);
+size_t d3f_conv_winograd_filter_bytes(const d3f_conv_desc* d);
+size_t d3f_conv_winograd_stats_floats(const d3f_conv_desc* d, int* tiles);
+int d3f_conv_winograd_pack(const d3f_conv_desc* d, const float* w, void* u, void* stream);
+int d3f_conv_winograd_forward(const d3f_conv_desc* d, const void* src0, const void* u, void* y, float* stats,
+                              const float* scale, const float* shift, const void* residual, int relu, void* stream);
 /* dx over the conv input: channels [0,C0) -> dx0, [C0,C0+C1) -> dx1; acc*: add to the destination instead of
  * overwriting.  With upsample0, dx0 is the gradient of the LOW-resolution source [B][H/2][W/2][C0] when the layer
  * runs with the up-sampling folded into pre-summed weights (d3f_conv_upsample_folded() == 1: 3x3, stride 1, pad 1,

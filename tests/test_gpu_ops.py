@@ -148,6 +148,80 @@ def test_conv_large_tiles(ops):
     _conv_case(ops, 4, 128, 128, 32, 0, 64, 3, 1, 1, False, seed=1)
 
 
+# Winograd F(2x2, 3x3) forward on its own (d3f_conv_winograd_*; the whole-network plan takes it from 256 workgroups of
+# 16x16 pixels x 64 filters up): B, H, W, Cin, Cout, applies
+WINOGRAD_CASES = [
+    (1, 16, 16, 16, 64, False),      # one workgroup, one 16-channel chunk: every image border inside one patch
+    (2, 32, 48, 48, 128, False),     # odd chunk count (3), two filter blocks, non-square
+    (4, 128, 128, 64, 64, True),     # exactly 256 workgroups: the first shape the plan takes
+    (4, 128, 112, 64, 64, False),    # 224 workgroups, just below: the plan keeps the implicit GEMM
+    (64, 32, 32, 128, 128, True),    # layer2 at 256x256, bs 64 (BASELINE configs[4]): 512 workgroups, 8 chunks
+]
+
+
+@pytest.mark.parametrize("case", WINOGRAD_CASES, ids=[str(c) for c in WINOGRAD_CASES])
+def test_conv_winograd_forward(ops, case):
+    """conv2d of a BasicBlock (d3f/train_denoiser/lit_module.py:117) through conv_winograd_kernel alone: raw output +
+    BatchNorm statistics rows (train mode) and the folded-BatchNorm epilogue with / without residual and ReLU (eval
+    mode), held to the same 1e-5 as every other contraction; the plan's selection rule at its threshold."""
+    B, H, W, Cin, Cout, applies = case
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    y_ref = F.conv2d(x, w, None, 1, 1)
+    d = ops.make_desc(B, H, W, Cin, 0, Cout, 3, 1, 1)
+    assert ops.conv_winograd_applies(d) == applies
+    xs = to_nhwc(x).cuda()
+    u = ops.conv_winograd_pack(d, w.cuda())
+    y, stats, tiles = ops.conv_winograd_forward(d, xs, u)
+    torch.cuda.synchronize()
+    assert tiles == B * (H // 16) * (W // 16)
+    assert rel_l2(to_nchw(y.cpu()), y_ref) < TOL_CONV, ("winograd fwd", rel_l2(to_nchw(y.cpu()), y_ref))
+    st = stats.view(tiles, -1, 2).double().sum(0).cpu()
+    ref_s1, ref_s2 = y_ref.double().sum((0, 2, 3)), (y_ref.double() ** 2).sum((0, 2, 3))
+    assert max_rel(st[:Cout, 1], ref_s2) < 1e-5
+    assert (st[:Cout, 0] - ref_s1).abs().max() < 1e-3 * (1 + ref_s2.sqrt().max())
+    # the implicit GEMM (what d3f_conv_forward runs, and what the plan keeps below the threshold) on the same operands
+    wf, _ = ops.pack_weights(d, w.cuda(), dgrad=False)
+    y_ig, _, _ = ops.conv_forward(d, xs, None, wf)
+    assert rel_l2(to_nchw(y_ig.cpu()), y_ref) < TOL_CONV
+    assert rel_l2(y.cpu(), y_ig.cpu()) < TOL_CONV
+    # eval epilogue: relu?(conv * scale + shift + residual?)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(B, Cout, H, W, generator=g)
+    for with_res, relu in ((False, False), (False, True), (True, True), (True, False)):
+        ref = y_ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if with_res:
+            ref = ref + res
+        if relu:
+            ref = ref.clamp_min(0)
+        out, st2, _ = ops.conv_winograd_forward(d, xs, u, scale=scale.cuda(), shift=shift.cuda(),
+                                                residual=to_nhwc(res).cuda() if with_res else None, relu=relu)
+        assert st2 is None
+        assert rel_l2(to_nchw(out.cpu()), ref) < TOL_CONV, ("winograd eval", with_res, relu)
+        if relu:
+            assert (out >= 0).all()
+
+
+def test_conv_winograd_rejects_shapes_it_cannot_run(ops):
+    from denoising_diffusion_deep_fake_amd._lib import D3FError
+    for bad in (ops.make_desc(1, 16, 24, 16, 0, 64, 3, 1, 1),     # width not a multiple of 16
+                ops.make_desc(1, 16, 16, 16, 0, 32, 3, 1, 1),     # filters not a multiple of 64
+                ops.make_desc(1, 16, 16, 8, 0, 64, 3, 1, 1),      # channels not a multiple of 16
+                ops.make_desc(1, 16, 16, 16, 0, 64, 3, 2, 1),     # stride 2
+                ops.make_desc(1, 16, 16, 16, 16, 64, 3, 1, 1)):   # concatenated source
+        assert not ops.conv_winograd_applies(bad)
+        with pytest.raises(D3FError):
+            ops.conv_winograd_pack(bad, torch.zeros(bad.Cout, bad.CinReal, 3, 3, device="cuda"))
+    assert not ops.conv_winograd_applies(ops.make_desc(4, 128, 128, 64, 0, 64, 3, 1, 1), ops.BF16)
+    # residual / ReLU without the eval epilogue's scale and shift
+    d = ops.make_desc(1, 16, 16, 16, 0, 64, 3, 1, 1)
+    u = ops.conv_winograd_pack(d, torch.zeros(64, 16, 3, 3, device="cuda"))
+    with pytest.raises(D3FError):
+        ops.conv_winograd_forward(d, torch.zeros(1, 16, 16, 16, device="cuda"), u, relu=True)
+
+
 def test_batchnorm_train_fwd_bwd(ops):
     g = torch.Generator().manual_seed(3)
     B, C, H, W = 4, 64, 12, 12
