@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace d3f {
 
@@ -31,19 +32,37 @@ bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
   return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= BNF_MAX_ROWS;
 }
 
+// four channels of one tensor row as they sit in memory (fp32: 16 bytes, bf16: 8 bytes): what a prefetched batch keeps in
+// registers until its turn
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt4(const float4& v) { return v; }
+__device__ __forceinline__ float4 cvt4(const uint2& v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+
 // sums the partial rows [rows][ld][2] of channels [c0, c0 + 32) in f64: thread (rl = tid / 16, q = tid % 16) owns the
 // float4 q of the slab (channels c0 + 2q, c0 + 2q + 1; sum, second sum each) of rows rl, rl + 16, ...; the 16 row
-// lanes are then added in lane order.  tot[2 * ch + which] for ch < 32.
+// lanes are then added in lane order.  tot[2 * ch + which] for ch < 32.  `behind_first_loads()` runs once, right behind
+// the issue of the first batch of partial-row loads: the streaming pass puts the loads of its first rows there, so that
+// they travel while the reduce waits for its own (the coefficients do not depend on them).
+template <typename F>
 __device__ __forceinline__ void slab_reduce(const float* __restrict__ partial, int rows, int ld, int c0,
-                                            double (&red)[16][64], double (&tot)[64]) {
+                                            double (&red)[16][64], double (&tot)[64], F behind_first_loads) {
   const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const float* base = partial + ((long)c0 * 2 + q * 4);
   int r = rl;
+  bool hooked = false;
   for (; r + 112 < rows; r += 128) {  // eight rows in flight (layer1-type layers bring 512 partial rows)
     float4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(base + (long)(r + 16 * j) * ld * 2);
+    if (!hooked) { behind_first_loads(); hooked = true; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w;
@@ -54,11 +73,13 @@ __device__ __forceinline__ void slab_reduce(const float* __restrict__ partial, i
     const float4 v1 = *reinterpret_cast<const float4*>(base + (long)(r + 16) * ld * 2);
     const float4 v2 = *reinterpret_cast<const float4*>(base + (long)(r + 32) * ld * 2);
     const float4 v3 = *reinterpret_cast<const float4*>(base + (long)(r + 48) * ld * 2);
+    if (!hooked) { behind_first_loads(); hooked = true; }
     a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
     a0 += (double)v1.x; a1 += (double)v1.y; a2 += (double)v1.z; a3 += (double)v1.w;
     a0 += (double)v2.x; a1 += (double)v2.y; a2 += (double)v2.z; a3 += (double)v2.w;
     a0 += (double)v3.x; a1 += (double)v3.y; a2 += (double)v3.z; a3 += (double)v3.w;
   }
+  if (!hooked) behind_first_loads();  // (fewer than 64 partial rows: in front of the tail's loads)
   for (; r < rows; r += 16) {
     const float4 v = *reinterpret_cast<const float4*>(base + (long)r * ld * 2);
     a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
@@ -81,7 +102,10 @@ __device__ __forceinline__ void slab_reduce(const float* __restrict__ partial, i
 // forward: statistics -> (mean, invstd, scale, shift, running stats) -> out = [relu](y * scale + shift [+ residual])
 // grid = (row blocks, C / 32); residual forms as bn_apply_kernel (pointwise.hip)
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// The streaming pass keeps TWO batches of U rows per thread in flight: the loads of batch i + 1 are issued in front of the
+// arithmetic and the stores of batch i, and batch 0 travels during the slab reduce -- the pass was latency-bound (a
+// layer1-type fp32 launch: 16 rows per thread = four dependent load -> store rounds behind the reduce, 10-13 us for 34 MB).
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     const float* __restrict__ stats, int stat_rows, int C, int Cpad, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
@@ -94,16 +118,33 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[2][BNF_SC];
+  typedef typename Raw4<T>::type raw_t;
+  constexpr int U = sizeof(T) == 4 ? 4 : 8;  // rows per batch: 2 x U x 16 (8) bytes per thread in flight
   const int tid = threadIdx.x, c0 = blockIdx.y * BNF_SC;
-  slab_reduce(stats, stat_rows, Cpad, c0, red, tot);
+  // streaming pass: thread (rr = tid / 8, v = tid % 8) owns channels c0 + 4v .. + 3 of rows rr, rr + 32, ...
+  const int v = tid & 7, rr = tid >> 3, cc = c0 + v * 4;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  const T* __restrict__ second = res != nullptr ? res : yr;
+  raw_t a[U], b[U], an[U], bn[U];
+  auto load = [&](raw_t (&ya)[U], raw_t (&yb)[U], long r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // rows past the block's end re-read its last row (never stored): straight-line loads
+      const long row = r + 32 * u < r1 ? r + 32 * u : r1 - 1;
+      ya[u] = ldraw(y + row * C + cc);
+      if (HAS2) yb[u] = ldraw(second + row * C + cc);
+    }
+  };
+  slab_reduce(stats, stat_rows, Cpad, c0, red, tot, [&]() { load(a, b, r0 + rr); });
   if (tid < BNF_SC) {  // same arithmetic as bn_finalize_kernel
     const int c = c0 + tid;
     const double mean = tot[2 * tid] / count;
     double var = tot[2 * tid + 1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma[c], b = beta[c];
-    const float sc = (float)((double)g * invstd), sf = (float)((double)b - mean * (double)g * invstd);
+    const float g = gamma[c], bt = beta[c];
+    const float sc = (float)((double)g * invstd), sf = (float)((double)bt - mean * (double)g * invstd);
     cf[0][tid] = sc;
     cf[1][tid] = sf;
     if (blockIdx.x == 0) {
@@ -119,52 +160,46 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     }
   }
   __syncthreads();
-  // streaming pass: thread (rr = tid / 8, v = tid % 8) owns channels c0 + 4v .. + 3 of rows rr, rr + 32, ...
-  const int v = tid & 7, rr = tid >> 3, cc = c0 + v * 4;
   float sc[4], sf[4], scr[4] = {0.f, 0.f, 0.f, 0.f}, sfr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     sc[k] = cf[0][v * 4 + k];
     sf[k] = cf[1][v * 4 + k];
-    if (yr != nullptr) {
+    if (HAS2 && res == nullptr) {
       scr[k] = scale_r[cc + k];
       sfr[k] = shift_r[cc + k];
     }
   }
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  long r1 = r0 + rows_per_block;
-  if (r1 > rows) r1 = rows;
-  const T* __restrict__ second = res != nullptr ? res : yr;
-  constexpr int U = 4;
   for (long r = r0 + rr; r < r1; r += 32 * U) {
-    float4 a[U], b[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long row = r + 32 * u;
-      if (row < r1) {
-        a[u] = ld4<T>(y + row * C + cc);
-        if (second != nullptr) b[u] = ld4<T>(second + row * C + cc);
-      }
-    }
+    if (r + 32 * U < r1) load(an, bn, r + 32 * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long row = r + 32 * u;
       if (row >= r1) continue;
-      float x[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+      const float4 ya = cvt4(a[u]);
+      float x[4] = {ya.x, ya.y, ya.z, ya.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = x[k] * sc[k] + sf[k];
-      if (res != nullptr) {
-        x[0] += b[u].x; x[1] += b[u].y; x[2] += b[u].z; x[3] += b[u].w;
-      } else if (yr != nullptr) {
-        const float t[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+      if (HAS2) {
+        const float4 yb = cvt4(b[u]);
+        if (res != nullptr) {
+          x[0] += yb.x; x[1] += yb.y; x[2] += yb.z; x[3] += yb.w;
+        } else {
+          const float t[4] = {yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] += t[k] * scr[k] + sfr[k];
+          for (int k = 0; k < 4; ++k) x[k] += t[k] * scr[k] + sfr[k];
+        }
       }
       if (relu) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
       }
       st4<T>(out + row * C + cc, make_float4(x[0], x[1], x[2], x[3]));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = an[u];
+      if (HAS2) b[u] = bn[u];
     }
   }
 }
@@ -191,16 +226,20 @@ int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C
   const int slabs = C / BNF_SC;
   const long rpb = rows_per_block_for(rows, slabs, dtype);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
-  if (dtype == D3F_F32)
-    hipLaunchKernelGGL(bn_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
-                       (const float*)y, (const float*)res, (const float*)yr, scale_r, shift_r, relu, (float*)out, rows,
-                       rpb);
-  else
-    hipLaunchKernelGGL(bn_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
-                       (const bf16_t*)y, (const bf16_t*)res, (const bf16_t*)yr, scale_r, shift_r, relu, (bf16_t*)out,
-                       rows, rpb);
+  const bool has2 = res != nullptr || yr != nullptr;
+  auto go = [&](auto kernel, auto* typed) {
+    typedef std::remove_pointer_t<decltype(typed)> T;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad, (double)count, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean, invstd, scale, shift, (const T*)y, (const T*)res,
+                       (const T*)yr, scale_r, shift_r, relu, (T*)out, rows, rpb);
+  };
+  if (dtype == D3F_F32) {
+    if (has2) go(bn_finalize_apply_kernel<float, true>, (float*)nullptr);
+    else go(bn_finalize_apply_kernel<float, false>, (float*)nullptr);
+  } else {
+    if (has2) go(bn_finalize_apply_kernel<bf16_t, true>, (bf16_t*)nullptr);
+    else go(bn_finalize_apply_kernel<bf16_t, false>, (bf16_t*)nullptr);
+  }
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -209,20 +248,40 @@ int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C
 // backward: partial sums of dz, dz * xhat -> (dgamma, dbeta, coefficients) ->
 //   dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)),  dz = dA * [a > 0]   (as bn_bwd_apply_kernel)
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// FROM_A: the ReLU mask is read from the stored activation (layers with a residual add; else it is recomputed from
+// y * mask_scale + mask_shift, or there is no ReLU); RD_DRES: dres is accumulated into.  Template flags so that a launch
+// keeps only the tensors it reads in registers: two batches of U rows per thread in flight as in the forward pass.
+template <typename T, bool FROM_A, bool RD_DRES>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     const float* __restrict__ partial, int nblocks, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, const T* __restrict__ dA,
     const T* __restrict__ a, const T* __restrict__ y, T* __restrict__ dy, T* __restrict__ dres,
-    int dres_acc, long rows, long rows_per_block, const float* __restrict__ mask_scale,
+    long rows, long rows_per_block, const float* __restrict__ mask_scale,
     const float* __restrict__ mask_shift) {
   chain_priority();
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[3][BNF_SC];
+  typedef typename Raw4<T>::type raw_t;
+  constexpr int U = BNF_BWD_U;
   const int tid = threadIdx.x, c0 = blockIdx.y * BNF_SC;
-  slab_reduce(partial, nblocks, C, c0, red, tot);
+  const int v = tid & 7, rr = tid >> 3, cc = c0 + v * 4;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  raw_t g4[U], y4[U], a4[U], d4[U], g4n[U], y4n[U], a4n[U], d4n[U];
+  auto load = [&](raw_t (&gg)[U], raw_t (&yy)[U], raw_t (&aa)[U], raw_t (&dd)[U], long r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // rows past the block's end re-read its last row (never stored): straight-line loads
+      const long row = r + 32 * u < r1 ? r + 32 * u : r1 - 1;
+      gg[u] = ldraw(dA + row * C + cc);
+      yy[u] = ldraw(y + row * C + cc);
+      if (FROM_A) aa[u] = ldraw(a + row * C + cc);
+      if (RD_DRES) dd[u] = ldraw(dres + row * C + cc);
+    }
+  };
+  slab_reduce(partial, nblocks, C, c0, red, tot, [&]() { load(g4, y4, a4, d4, r0 + rr); });
   if (tid < BNF_SC) {  // same arithmetic as bn_bwd_finalize_kernel
     const int c = c0 + tid;
     const double s1 = tot[2 * tid], s2 = tot[2 * tid + 1];
@@ -242,7 +301,6 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     }
   }
   __syncthreads();
-  const int v = tid & 7, rr = tid >> 3, cc = c0 + v * 4;
   float k0[4], k1[4], k2[4], mu[4], is[4], msc[4] = {0.f, 0.f, 0.f, 0.f}, msf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -251,42 +309,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     k2[k] = cf[2][v * 4 + k];
     mu[k] = mean[cc + k];
     is[k] = invstd[cc + k];
-    if (mask_scale != nullptr) {
+    if (!FROM_A && mask_scale != nullptr) {
       msc[k] = mask_scale[cc + k];
       msf[k] = mask_shift[cc + k];
     }
   }
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  long r1 = r0 + rows_per_block;
-  if (r1 > rows) r1 = rows;
-  const bool from_a = mask_scale == nullptr && a != nullptr;
-  const bool rd_dres = dres != nullptr && dres_acc;
-  constexpr int U = BNF_BWD_U;
   for (long r = r0 + rr; r < r1; r += 32 * U) {
-    float4 g4[U], y4[U], a4[U], d4[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long row = r + 32 * u;
-      if (row < r1) {
-        g4[u] = ld4<T>(dA + row * C + cc);
-        y4[u] = ld4<T>(y + row * C + cc);
-        if (from_a) a4[u] = ld4<T>(a + row * C + cc);
-        if (rd_dres) d4[u] = ld4<T>(dres + row * C + cc);
-      }
-    }
+    if (r + 32 * U < r1) load(g4n, y4n, a4n, d4n, r + 32 * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long row = r + 32 * u;
       if (row >= r1) continue;
-      float g[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
-      const float yy[4] = {y4[u].x, y4[u].y, y4[u].z, y4[u].w};
-      if (mask_scale != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
-      } else if (from_a) {
-        const float aa[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
+      const float4 gv = cvt4(g4[u]), yv = cvt4(y4[u]);
+      float g[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+      if (FROM_A) {
+        const float4 av = cvt4(a4[u]);
+        const float aa[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = aa[k] > 0.f ? g[k] : 0.f;
+      } else if (mask_scale != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = (yy[k] * msc[k] + msf[k]) > 0.f ? g[k] : 0.f;
       }
       float o[4];
 #pragma unroll
@@ -296,11 +340,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
       }
       st4<T>(dy + row * C + cc, make_float4(o[0], o[1], o[2], o[3]));
       if (dres != nullptr) {
-        if (dres_acc) {
-          g[0] += d4[u].x; g[1] += d4[u].y; g[2] += d4[u].z; g[3] += d4[u].w;
+        if (RD_DRES) {
+          const float4 dv = cvt4(d4[u]);
+          g[0] += dv.x; g[1] += dv.y; g[2] += dv.z; g[3] += dv.w;
         }
         st4<T>(dres + row * C + cc, make_float4(g[0], g[1], g[2], g[3]));
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g4[u] = g4n[u];
+      y4[u] = y4n[u];
+      if (FROM_A) a4[u] = a4n[u];
+      if (RD_DRES) d4[u] = d4n[u];
     }
   }
 }
@@ -315,16 +367,23 @@ int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, i
   const int slabs = C / BNF_SC;
   const long rpb = rows_per_block_for(rows, slabs, dtype);
   const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
-  if (dtype == D3F_F32)
-    hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<float>, grid, dim3(256), 0, stream, partial, nblocks, C,
-                       (double)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, (const float*)dA,
-                       (const float*)a, (const float*)y, (float*)dy, (float*)dres, dres_acc, rows, rpb, mask_scale,
-                       mask_shift);
-  else
-    hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, partial, nblocks, C,
-                       (double)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, (const bf16_t*)dA,
-                       (const bf16_t*)a, (const bf16_t*)y, (bf16_t*)dy, (bf16_t*)dres, dres_acc, rows, rpb, mask_scale,
-                       mask_shift);
+  const bool from_a = mask_scale == nullptr && a != nullptr;
+  const bool rd_dres = dres != nullptr && dres_acc;
+  auto go = [&](auto kernel, auto* typed) {
+    typedef std::remove_pointer_t<decltype(typed)> T;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, partial, nblocks, C, (double)count, gamma, mean, invstd, dgamma,
+                       dbeta, accumulate, coef, (const T*)dA, (const T*)a, (const T*)y, (T*)dy, (T*)dres, rows, rpb,
+                       mask_scale, mask_shift);
+  };
+  auto pick = [&](auto* typed) {
+    typedef std::remove_pointer_t<decltype(typed)> T;
+    if (from_a && rd_dres) go(bn_bwd_finalize_apply_kernel<T, true, true>, typed);
+    else if (from_a) go(bn_bwd_finalize_apply_kernel<T, true, false>, typed);
+    else if (rd_dres) go(bn_bwd_finalize_apply_kernel<T, false, true>, typed);
+    else go(bn_bwd_finalize_apply_kernel<T, false, false>, typed);
+  };
+  if (dtype == D3F_F32) pick((float*)nullptr);
+  else pick((bf16_t*)nullptr);
   D3F_HIP(hipGetLastError());
   return 0;
 }
