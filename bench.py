@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the contraction kernels with HIP events in the timed region")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--overlap-tail", default="off", choices=["on", "off"],
+                    help="FusedAdam(overlap_tail=...): Adam over every gradient bucket but the last inside backward (single "
+                         "process; a data-parallel reducer keeps the whole update in step()).  Bit-identical values.")
     ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict"],
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
@@ -124,7 +127,8 @@ def alt_dtype(args, dev, dtype):
     lit = LitModule(batch_size=args.batch, learning_rate=0.02, max_epochs=100, cosine_scheduler_max_epoch=100,
                     num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
                     mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
-                    augment=False, precision=dtype, graph_step=wants_graph_step(args, dtype, 1)).to(dev).train()
+                    augment=False, precision=dtype, graph_step=wants_graph_step(args, dtype, 1),
+                    optimizer_overlap_tail=args.overlap_tail == "on").to(dev).train()
     (opt,), _ = lit.configure_optimizers()
     lit.attach_optimizers([opt])
     nb = 4
@@ -435,7 +439,8 @@ def main():
                     num_workers=0, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
                     mean=[128, 128, 128], std=[128, 128, 128], synthetic=True, image_size=args.size,
                     augment=False, precision=args.dtype,
-                    graph_step=wants_graph_step(args, args.dtype, world)).to(dev).train()
+                    graph_step=wants_graph_step(args, args.dtype, world),
+                    optimizer_overlap_tail=args.overlap_tail == "on").to(dev).train()
     (opt,), _ = lit.configure_optimizers()
     lit.attach_optimizers([opt])
     DataParallel(lit.model, opt)
@@ -525,6 +530,9 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": round(lossv, 5),
                    # True: the optimiser step is replayed from one captured hipGraph (--graph-step; never at N > 1)
                    "graph_step": not lit.automatic_optimization,
+                   # True: Adam over every gradient bucket but the last ran inside backward (FusedAdam(overlap_tail=True));
+                   # False at N > 1 (the reducer keeps the whole update in step()) and under --overlap-tail off
+                   "adam_overlap_tail": bool(opt.overlap_tail and world == 1 and lit.automatic_optimization),
                    # what the collective layer saw (None at N=1: no process group, no exchange step)
                    "backend": dist.get_backend() if world > 1 else None,
                    "ranks_seen": dist.get_world_size() if world > 1 else 1,

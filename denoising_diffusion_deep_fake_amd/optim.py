@@ -3,6 +3,9 @@
 FusedAdam : torch.optim.Adam(params, lr, betas) as the reference configures it
             (d3f/train_denoiser/lit_module.py:95; d3f/train_deep_fake/lit_module.py:116-120) in ONE
             kernel launch over all 24.4 M parameters (csrc/optim.hip) instead of ~140 per-tensor updates.
+            overlap_tail=True (opt-in): the update of every gradient bucket but the last runs INSIDE backward, behind the
+            chain's last kernel and next to the last bucket's weight gradients on the side stream; step() updates the
+            rest.  Same values, bit for bit.
 EMA       : ema_pytorch.EMA(model, beta, update_every, include_online_model=False) semantics
             (d3f/train_deep_fake/lit_module.py:62-70,185; defaults update_after_step=100, inv_gamma=1,
             power=2/3, min_value=0 -- SURVEY.md Appendix A.3) with the lerp as one launch per flat buffer.
@@ -16,7 +19,15 @@ from .unet import Unet
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, module=None, grad_scale=1.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, module=None, grad_scale=1.0, overlap_tail=False):
+        """overlap_tail: optimizer-in-backward for the leading gradient buckets (Unet.set_early_update).  The contract
+        the caller accepts with it: every backward() is followed by exactly one step() with unchanged lr / betas / eps
+        (Lightning's automatic optimisation, this package's Trainer and bench.py do that); the parameters of layer3,
+        layer4, the decoder and the head already hold their updated values when backward() returns; .grad is complete
+        and untouched as always.  A data-parallel reducer, or gradients that do not land in the flat buffer directly
+        (.grad not None before backward: zero_grad(set_to_none=False)), switch the early part off by themselves (the
+        whole update then runs in step() as without the flag); a second backward() before step() (gradient accumulation),
+        changed hyper-parameters or cleared gradients between backward() and step() raise in step()."""
         params = list(params)
         # the param-group keys of torch.optim.Adam, so that its load_state_dict accepts a state_dict saved here (and
         # the other way round); the variants behind the switches are not implemented by the one-launch update
@@ -33,6 +44,39 @@ class FusedAdam(torch.optim.Optimizer):
         self._step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
+        self.overlap_tail = bool(overlap_tail)
+        self._early = None  # (lo, hi, hyper-parameters, gradient buffer) of an update already applied inside backward
+        if self.overlap_tail:
+            module.set_early_update(self._early_update)
+
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad; the set_to_none form without its per-parameter bookkeeping (143 parameters:
+        ~0.1 ms of host time per step on the launch-bound configurations)"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for p in self.module._param_list:
+            p.grad = None
+
+    def _hyper(self):
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise NotImplementedError("FusedAdam implements plain Adam (weight_decay=0, amsgrad=False, maximize=False), "
+                                      "which is what the reference configures")
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(self.grad_scale))
+
+    @torch.no_grad()
+    def _early_update(self, grads, lo, hi):
+        """Unet.set_early_update hook: gradients [lo, hi) are final on the current stream"""
+        if self._early is not None:
+            return  # (a second backward before step(): step() refuses the mixed update)
+        flat = self.module.flat_params
+        if self.exp_avg is None or self.exp_avg.data_ptr() == 0 or self.exp_avg.device != flat.device:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+        hyper = self._hyper()
+        ops.adam_step(flat[lo:hi], grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], hyper[0], hyper[1], hyper[2],
+                      hyper[3], self._step + 1, hyper[4])
+        self._early = (lo, hi, hyper, grads.data_ptr(), self.module._rt.get("backward_calls", 0))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,8 +90,14 @@ class FusedAdam(torch.optim.Optimizer):
         plist = m._param_list
         first = plist[0].grad
         if first is None:
+            if self._early is not None:
+                raise RuntimeError("FusedAdam(overlap_tail=True): the gradients were cleared between backward() and "
+                                   "step(), but part of this step's update already ran inside backward()")
             return loss  # nothing to do (all grads cleared) -- same as torch.optim.Adam
         if first.data_ptr() != grads.data_ptr():
+            if self._early is not None:
+                raise RuntimeError("FusedAdam(overlap_tail=True): gradients were accumulated outside the flat buffer "
+                                   "after part of this step's update already ran inside backward()")
             # gradients were accumulated outside the flat buffer: gather them
             off = 0
             for p in plist:
@@ -56,13 +106,25 @@ class FusedAdam(torch.optim.Optimizer):
         if self.exp_avg is None or self.exp_avg.data_ptr() == 0 or self.exp_avg.device != flat.device:
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
-        g = self.param_groups[0]
-        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
-            raise NotImplementedError("FusedAdam implements plain Adam (weight_decay=0, amsgrad=False, maximize=False), "
-                                      "which is what the reference configures")
+        hyper = self._hyper()
         self._step += 1
-        ops.adam_step(flat, grads, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
-                      float(g["betas"][1]), float(g["eps"]), self._step, float(self.grad_scale))
+        early, self._early = self._early, None
+        if early is None:
+            ranges = [(0, flat.numel())]
+        else:
+            lo, hi, used, gptr, calls = early
+            if calls != m._rt.get("backward_calls", 0):
+                raise RuntimeError("FusedAdam(overlap_tail=True): another backward() ran before step(), but part of this "
+                                   "step's update already ran inside the first one (gradient accumulation needs "
+                                   "overlap_tail=False)")
+            if used != hyper or gptr != grads.data_ptr():
+                raise RuntimeError("FusedAdam(overlap_tail=True): lr / betas / eps / grad_scale or the gradient buffer "
+                                   f"changed between backward() and step() ({used} -> {hyper}); part of this step's "
+                                   "update already ran inside backward() with the old values")
+            ranges = [r for r in ((0, lo), (hi, flat.numel())) if r[1] > r[0]]
+        for b, e in ranges:
+            ops.adam_step(flat[b:e], grads[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], hyper[0], hyper[1], hyper[2],
+                          hyper[3], self._step, hyper[4])
         m.mark_params_changed()
         return loss
 

@@ -136,8 +136,11 @@ class LitModule(LightningModule):
     def configure_optimizers(self):
         p = self.hparams
         b1, b2 = p.adam_b1, p.adam_b2
-        optimizer_a = FusedAdam(self.model_a.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_a)
-        optimizer_b = FusedAdam(self.model_b.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_b)
+        tail = bool(p.get("optimizer_overlap_tail", False))  # FusedAdam docstring: part of the update inside backward
+        optimizer_a = FusedAdam(self.model_a.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_a,
+                                overlap_tail=tail)
+        optimizer_b = FusedAdam(self.model_b.parameters(), lr=p.learning_rate, betas=(b1, b2), module=self.model_b,
+                                overlap_tail=tail)
         scheduler_a = schedulers.CosineAnnealingLR(optimizer_a, T_max=p.cosine_scheduler_max_epoch)
         scheduler_b = schedulers.CosineAnnealingLR(optimizer_b, T_max=p.cosine_scheduler_max_epoch)
         return [optimizer_a, optimizer_b], [scheduler_a, scheduler_b]

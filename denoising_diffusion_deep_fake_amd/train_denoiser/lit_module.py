@@ -96,7 +96,10 @@ class LitModule(LightningModule):
 
     def configure_optimizers(self):
         p = self.hparams
-        optimizer = FusedAdam(self.model.parameters(), lr=p.learning_rate, module=self.model)
+        # optimizer_overlap_tail: true -- the update of layer3 / layer4 / decoder / head runs inside backward next to the
+        # last gradient bucket (FusedAdam docstring: one step() per backward(); bit-identical values)
+        optimizer = FusedAdam(self.model.parameters(), lr=p.learning_rate, module=self.model,
+                              overlap_tail=bool(p.get("optimizer_overlap_tail", False)))
         scheduler = schedulers.CosineAnnealingLR(optimizer, T_max=p.cosine_scheduler_max_epoch)
         return [optimizer], [scheduler]
 

@@ -206,7 +206,9 @@ class _Lease:
 
 class _UnetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, module, engine, *params):
+    def forward(ctx, x, module, engine, anchor):
+        # `anchor`: ONE parameter that requires grad -- enough for autograd to record the node and call backward, which
+        # writes every parameter's .grad itself; handing all 143 parameters to apply() cost ~0.15 ms of host time per step
         ctx.module, ctx.engine = module, engine
         out = module._run_forward(engine, x, training=True)
         ctx.serial = engine.serial
@@ -225,7 +227,7 @@ class _UnetFunction(torch.autograd.Function):
             raise D3FError("the workspace of this forward pass was overwritten by a later forward before backward ran")
         ctx.module._run_backward(eng, grad_out)
         ctx.lease.release()
-        return (None, None, None) + (None,) * len(ctx.module._param_list)
+        return (None, None, None, None)  # every .grad was set by _run_backward (views of the flat gradient buffer)
 
 
 class Unet(nn.Module):
@@ -340,7 +342,7 @@ class Unet(nn.Module):
                     setattr(bn, attr, view)
                 flat_nbt[i] = bn.num_batches_tracked.to(device)
                 bn.num_batches_tracked = flat_nbt[i]
-        rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, dirty=True,
+        rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, grad_views=None, dirty=True,
                   params=[named[name] for name, _, _ in ptable])
         for p in named.values():
             p.grad = None
@@ -389,6 +391,16 @@ class Unet(nn.Module):
         """fn(segment_index, flat_grad_slice) is called as soon as a gradient bucket is final
         (data-parallel all-reduce overlap); None disables."""
         self._rt["grad_sync"] = fn
+
+    def set_early_update(self, fn):
+        """fn(flat_grad, lo, hi) is called INSIDE backward, on the caller's stream behind the chain's last kernel and a
+        wait for "the gradients of every bucket but the last are final" (flat range [lo, hi): layer3, layer4, decoder and
+        head -- 94 % of the parameters), BEFORE the join with the side stream on which the last bucket's weight gradients
+        (layer2, layer1, stem) are still running.  An optimiser that updates [lo, hi) in the hook runs next to that
+        tail instead of behind it (FusedAdam(overlap_tail=True)).  Only
+        taken when the gradients land in the flat buffer directly (every .grad None before backward) and no
+        data-parallel reducer is attached; None disables."""
+        self._rt["early_update"] = fn
 
     # -- engine -------------------------------------------------------------------------------------
     MAX_LIVE_GRAPHS = 4  # workspaces (2 GB each at bs 16, 256x256) per shape that may hold un-backwarded graphs
@@ -445,9 +457,29 @@ class Unet(nn.Module):
         direct = all(p.grad is None for p in params)
         if rt["flat_grad"] is None:
             rt["flat_grad"] = torch.empty_like(rt["flat"])
+            rt["grad_views"] = None
         target = rt["flat_grad"] if direct else torch.empty_like(rt["flat"])
         sync = rt["grad_sync"]
-        if sync is None:
+        rt["backward_calls"] = rt.get("backward_calls", 0) + 1
+        early = rt.get("early_update") if (sync is None and direct and eng.nseg > 1) else None
+        side = eng.side_stream(grad_out.device) if early is not None else None
+        if early is not None and side is not None:
+            # every bucket is enqueued without a join; the leading buckets' gradients are final on the side stream at the
+            # event, and the hook's update runs on THIS stream behind the chain's last kernel -- next to the last bucket's
+            # weight gradients, which are still running on the side stream -- before the join that step() would wait for
+            last = eng.nseg - 1
+            lo, hi = min(b for b, _ in eng.seg_ranges[:last]), max(e for _, e in eng.seg_ranges[:last])
+            if sum(e - b for b, e in eng.seg_ranges[:last]) != hi - lo:
+                raise D3FError("early update: the leading gradient buckets are not one contiguous range")
+            check(L.d3f_unet_backward_nojoin(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target), ptr(eng.workspace),
+                                             0, last, stream_ptr()))
+            final = side.record_event()
+            check(L.d3f_unet_backward_nojoin(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target), ptr(eng.workspace),
+                                             last, eng.nseg, stream_ptr()))
+            torch.cuda.current_stream().wait_event(final)
+            early(target, lo, hi)
+            check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
+        elif sync is None:
             check(L.d3f_unet_backward(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target), ptr(eng.workspace),
                                       0, eng.nseg, stream_ptr()))
         else:
@@ -469,12 +501,21 @@ class Unet(nn.Module):
                         sync(s, target[b:e])
             check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
         ptable = self._table()[0]
+        if direct:
+            # the same 143 view tensors of the flat gradient buffer every step (making them anew cost ~0.3 ms of host time)
+            views = rt.get("grad_views")
+            if views is None or views[0].data_ptr() != target.data_ptr():
+                views = rt["grad_views"] = [target[off:off + p.numel()].view(shape) for (_, shape, off), p in zip(ptable, params)]
+            for p, view in zip(params, views):
+                if p.requires_grad:
+                    p.grad = view
+            return
         for (name, shape, off), p in zip(ptable, params):
             if not p.requires_grad:
                 continue
             view = target[off:off + p.numel()].view(shape)
             if p.grad is None:
-                p.grad = view if direct else view.clone()
+                p.grad = view.clone()
             else:
                 p.grad.add_(view)
 
@@ -505,7 +546,7 @@ class Unet(nn.Module):
                 raise D3FError("backward through an eval-mode Unet is not supported (BatchNorm is folded)")
             if x.requires_grad:
                 raise D3FError("gradient w.r.t. the network input is not computed by the HIP path")
-            return _UnetFunction.apply(xin, self, eng, *params)
+            return _UnetFunction.apply(xin, self, eng, next(p for p in params if p.requires_grad))
         return self._run_forward(eng, xin, training=self.training)
 
     @torch.no_grad()

@@ -68,8 +68,8 @@ static void run(const char* what, const float* din, float* dout, unsigned long l
 int main() {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  printf("%s, %d CUs, clockRate %d kHz; nominal fp32 MFMA peak = CUs x 4 SIMD x 256 FLOP/clk x 2.4 GHz = %.1f TFLOP/s\n", prop.name,
-         prop.multiProcessorCount, prop.clockRate, prop.multiProcessorCount * 4 * 256 * 2.4e9 * 1e-12);
+  printf("%s, %d CUs, clockRate %d kHz; nominal fp32 MFMA peak = CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz = %.1f TFLOP/s\n", prop.gcnArchName,
+         prop.multiProcessorCount, prop.clockRate, prop.multiProcessorCount * 4 * 64 * 2.4e9 * 1e-12);
   std::vector<float> h(4096);
   float *dz, *dr, *dw, *dout;
   unsigned long long* dclk;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void fused(Bar* b, float* data, int kb, int it
     else barrier_xcd(b, xcc, n_on, nx, xphase);
     if (ld_relaxed(b->fail)) return;
     const float got = read_phase(data, kb);
-    if (got != (float)(it + (int)(threadIdx.x & 31)) && kb > 0) atomicAdd(bad, 1u);  // a stale read = a broken barrier
+    if (got != (float)(it + (int)((threadIdx.x & 31) >> 2)) && kb > 0) atomicAdd(bad, 1u);  // a stale read = a broken barrier (float4 i of the record was written by thread i)
     acc += got;
     // (the next iteration's writes must not overtake other workgroups' reads of this one: second barrier, not timed apart)
     if (FORM == 0) barrier_flat(b, gridDim.x, phase);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void fused(Bar* b, float* data, int kb, int it
 __global__ __launch_bounds__(256) void k_write(float* data, int kb, int it) { write_phase(data, kb, it); }
 __global__ __launch_bounds__(256) void k_read(float* data, int kb, int it, unsigned* bad, float* sink) {
   const float got = read_phase(data, kb);
-  if (got != (float)(it + (int)(threadIdx.x & 31)) && kb > 0) atomicAdd(bad, 1u);
+  if (got != (float)(it + (int)((threadIdx.x & 31) >> 2)) && kb > 0) atomicAdd(bad, 1u);
   if (got == 12345.f) sink[0] = got;
 }
 
@@ -129,8 +129,8 @@ int main() {
   CK(hipMemset(data, 0, data_bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 200;
-  printf("per iteration = write phase + dependency + read phase + dependency; 'per dependency' = (t - t(0 KB, launch form's kernels excluded)) / 2 is NOT taken:\n"
-         "the columns are whole-iteration times, compare forms at equal kb\n");
+  printf("one iteration = write phase + dependency + read phase + dependency (two grid barriers, or two kernel boundaries):\n"
+         "whole-iteration times, compare the forms at equal KB; at 0 KB half an iteration is the bare cost of one dependency\n");
   for (int blocks : {256, 512, 1024}) {
     for (int kb : {0, 4, 32, 64}) {
       float t[3] = {0, 0, 0};

@@ -570,6 +570,85 @@ def test_graph_train_step_is_bitwise_the_eager_step(dtype, shape):
     assert ref[0][-1] < ref[0][0]   # and it learns
 
 
+@pytest.mark.parametrize("dtype,shape", [("f32", (4, 64, 64)), ("bf16", (4, 64, 64)), ("f32", (16, 128, 128))],
+                         ids=["f32_4x64", "bf16_4x64", "f32_16x128"])
+def test_adam_overlap_tail_is_bitwise_the_plain_step(dtype, shape):
+    """FusedAdam(overlap_tail=True): the Adam update of every gradient bucket but the last runs inside backward() on the
+    engine's side stream, step() updates the rest -- parameters, moments, BatchNorm statistics, losses and the gradients
+    left in .grad must equal the plain step bit for bit (five steps, a learning-rate change in between; replaces
+    torch.optim.Adam.step at d3f/train_denoiser/lit_module.py:95 under Lightning's automatic optimisation)."""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    B, H, W = shape
+    hp = dict(HP_DENOISER, batch_size=B, image_size=H, precision=dtype, augment=False)
+    data = [synthetic_face_crops(B, (H, W), seed=30 + i, device="cuda") for i in range(2)]
+
+    def run(tail):
+        torch.manual_seed(5)
+        lit = LitModule(**dict(hp, optimizer_overlap_tail=tail)).cuda().train()
+        (opt,), _ = lit.configure_optimizers()
+        assert opt.overlap_tail == tail
+        torch.manual_seed(77)
+        losses, early = [], 0
+        for i in range(5):
+            if i == 3:
+                opt.param_groups[0]["lr"] *= 0.5
+            opt.zero_grad(set_to_none=True)
+            loss = lit.training_step({"image": data[i % 2], "index": None}, i)
+            loss.backward()
+            early += opt._early is not None
+            opt.step()
+            assert opt._early is None
+            losses.append(float(loss.item()))
+        m = lit.model
+        return (losses, m.flat_params.clone(), m.flat_bn_stats.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                m.flat_grads.clone(), opt._step, early)
+
+    ref, got = run(False), run(True)
+    assert ref[7] == 0 and got[7] == 5          # the early part really ran inside every backward
+    assert got[0] == ref[0] and got[6] == ref[6] == 5
+    for k in range(1, 6):
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_adam_overlap_tail_contract_violations_are_loud():
+    """gradient accumulation or a hyper-parameter change between backward() and step() raise instead of applying a mixed
+    update; gradients kept outside the flat buffer keep the whole update in step()"""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    hp = dict(HP_DENOISER, optimizer_overlap_tail=True)
+    x = synthetic_face_crops(4, 64, seed=3, device="cuda")
+    torch.manual_seed(1)
+    lit = LitModule(**hp).cuda().train()
+    (opt,), _ = lit.configure_optimizers()
+    # (a) a second backward before step() (gradient accumulation)
+    opt.zero_grad(set_to_none=True)
+    lit.training_step({"image": x, "index": None}, 0).backward()
+    assert opt._early is not None
+    lit.training_step({"image": x, "index": None}, 1).backward()
+    with pytest.raises(RuntimeError, match="another backward"):
+        opt.step()
+    # ... while gradients that do not land in the flat buffer directly keep the whole update in step()
+    torch.manual_seed(1)
+    lit = LitModule(**hp).cuda().train()
+    (opt,), _ = lit.configure_optimizers()
+    lit.training_step({"image": x, "index": None}, 0).backward()
+    opt.step()
+    opt.zero_grad(set_to_none=False)
+    lit.training_step({"image": x, "index": None}, 1).backward()
+    assert opt._early is None
+    opt.step()
+    # (b) lr changed between backward and step
+    torch.manual_seed(1)
+    lit = LitModule(**hp).cuda().train()
+    (opt,), _ = lit.configure_optimizers()
+    opt.zero_grad(set_to_none=True)
+    lit.training_step({"image": x, "index": None}, 0).backward()
+    opt.param_groups[0]["lr"] *= 0.5
+    with pytest.raises(RuntimeError, match="changed between backward"):
+        opt.step()
+
+
 def test_graph_step_metrics_rows_are_per_step_values(tmp_path):
     """The Trainer keeps logged device scalars until the next flush: with graph_step on every step's loss must be its own
     tensor (GraphTrainStep returns a stream-ordered copy, not a view of the buffer each replay overwrites) -- the rows
