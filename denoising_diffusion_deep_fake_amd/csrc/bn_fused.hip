@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 // rows per workgroup, whole passes of 32 rows.  Workgroups in all: ~256 for fp32 tensors, ~512 for bf16 (r03 sweep of
 // 64 ... 1024 with the chain's kernels at wave priority 3: fp32 256x256 8.88 / 8.38 / 8.30 / 8.24 / 8.28 / 8.30 / 8.35 ms
 // per step at 64 / 128 / 192 / 256 / 320 / 512 / 768 -- every workgroup repeats the slab reduce, fewer of them repeat it
-// less; bf16 4.83 / 4.58 / 4.55 at 128 / 256 / 512: half the bytes per row, the streaming part wants the parallelism)
+// less; bf16 4.83 / 4.58 / 4.55 at 128 / 256 / 512: half the bytes per row, the streaming part wants the parallelism;
+// re-swept in round 4 with two batches in flight: fp32 7.87 / 7.91 / 7.94 / 7.94 / 8.02 ms at 256 / 384 / 512 / 768 / 1024,
+// bf16 4.09 / 4.09 / 4.12 / 4.18 at 384 / 512 / 768 / 1024 -- unchanged optimum)
 static long rows_per_block_for(long rows, int slabs, int dtype) {
   const long wgs = dtype == D3F_F32 ? 256 : 512;
   long rb = std::max(1L, wgs / slabs);

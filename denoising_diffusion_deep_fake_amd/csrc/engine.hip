@@ -950,6 +950,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
   constexpr int defer = 3;
   std::vector<int> pending;
   int pending_segment = -1;
+  bool head_bias_pending = false;
   // Slab reduces: one launch right behind every layer (every unit owns its slab region).  One launch per gradient
   // bucket (47 -> 4-6 launches, same sums) was measured equal or slightly SLOWER per step (r03): the big launches at the
   // bucket ends delay the buckets' "gradients final" point and the stream's tail more than the 40 launches cost.
@@ -965,6 +966,13 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       D3F_HIP(hipStreamWaitEvent(side_, ev_dy_[next_event], 0));
       ++next_event;
       side_used = true;
+    }
+    if (head_bias_pending) {  // the head's bias gradient: two small launches that nothing on the chain waits for
+      const Unit& uh = units[head];
+      if (int rc = channel_sum_nchw_launch(dout, B, uh.Cout, (long)uh.Ho * uh.Wo, reinterpret_cast<float*>(ws + bsum_off),
+                                           grads + uh.bias_off, ws_stream))
+        return rc;
+      head_bias_pending = false;
     }
     for (int ui : pending) {
       const Unit& u = units[ui];
@@ -1001,9 +1009,13 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     char* dy = ws + u.dy_off;
     if (op.kind == BW_HEAD) {
       if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s)) return rc;
-      if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
-                                           reinterpret_cast<float*>(ws + bsum_off), grads + u.bias_off, s))
-        return rc;
+      if (skip_w) {  // (profiling ablation without weight-gradient launches: nothing would flush it)
+        if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
+                                             reinterpret_cast<float*>(ws + bsum_off), grads + u.bias_off, s))
+          return rc;
+      } else {
+        head_bias_pending = true;  // with the head's weight gradient, on the weight-gradient stream (flush_pending)
+      }
     } else {
       int nb = 0;
       float* mean = coef_ptr(ws, u, 0);
