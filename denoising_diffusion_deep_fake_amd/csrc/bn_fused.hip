@@ -23,6 +23,9 @@ namespace d3f {
 
 constexpr int BNF_SC = 32;         // channels per slab = one 128-byte line per tensor row
 constexpr int BNF_MAX_ROWS = 1024;  // partial rows a workgroup is asked to reduce (x 256 B): 512 / 1024 / 2048 within 0.2 % of each other; 2048 would take in the stem, whose 512 KB prologue per workgroup makes the pass 3x longer
+#ifndef BNF_FWD_U_F32
+#define BNF_FWD_U_F32 4  // fp32 rows per batch in the forward streaming pass (8: 7.855 / 7.831 / 7.856 ms against 7.866 / 7.860 / 7.843 with 4 -- no gain, 176 instead of 128 VGPRs)
+#endif
 #ifndef BNF_BWD_U
 #define BNF_BWD_U 2  // rows in flight per thread in the backward streaming pass (4: +0.4 % step time -- 142 VGPRs leave one workgroup per CU next to the weight-gradient stream)
 #endif  // partial rows a workgroup is asked to reduce (x 256 B)
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
   __shared__ double tot[64];
   __shared__ float cf[2][BNF_SC];
   typedef typename Raw4<T>::type raw_t;
-  constexpr int U = sizeof(T) == 4 ? 4 : 8;  // rows per batch: 2 x U x 16 (8) bytes per thread in flight
+  constexpr int U = sizeof(T) == 4 ? BNF_FWD_U_F32 : 8;  // rows per batch: 2 x U x 16 (8) bytes per thread in flight
   const int tid = threadIdx.x, c0 = blockIdx.y * BNF_SC;
   // streaming pass: thread (rr = tid / 8, v = tid % 8) owns channels c0 + 4v .. + 3 of rows rr, rr + 32, ...
   const int v = tid & 7, rr = tid >> 3, cc = c0 + v * 4;
@@ -209,7 +212,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 // per step at 64 / 128 / 192 / 256 / 320 / 512 / 768 -- every workgroup repeats the slab reduce, fewer of them repeat it
 // less; bf16 4.83 / 4.58 / 4.55 at 128 / 256 / 512: half the bytes per row, the streaming part wants the parallelism;
 // re-swept in round 4 with two batches in flight: fp32 7.87 / 7.91 / 7.94 / 7.94 / 8.02 ms at 256 / 384 / 512 / 768 / 1024,
-// bf16 4.09 / 4.09 / 4.12 / 4.18 at 384 / 512 / 768 / 1024 -- unchanged optimum)
+// bf16 4.09 / 4.09 / 4.12 / 4.18 at 384 / 512 / 768 / 1024 -- unchanged optimum; 512 / 768 / 1024 only for the tensors of 32 MB
+// and more (stem, decoder block 3): 7.89 / 7.91 / 7.90 against 7.87 / 7.89 -- no gain either)
 static long rows_per_block_for(long rows, int slabs, int dtype) {
   const long wgs = dtype == D3F_F32 ? 256 : 512;
   long rb = std::max(1L, wgs / slabs);
