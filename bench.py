@@ -561,8 +561,8 @@ def main():
         # ROOFLINE FIGURE: every launch of the dominant kernel (forward AND data gradient) of the sampled steps
         t_all, f_all, n_all = ms[0] + ms[1], fl[0] + fl[1], n[0] + n[1]
         ach = f_all / t_all / 1e9
-        traffic, tsrc = pmc_from_file("r03_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
-        busy, bsrc = pmc_from_file("r03_mfma_util.json", lambda d: next(
+        traffic, tsrc = pmc_from_file("r04_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
+        busy, bsrc = pmc_from_file("r04_mfma_util.json", lambda d: next(
             (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
