@@ -290,3 +290,36 @@ def test_division_by_multiply_high_is_exact(tmp_path):
                     str(root / "tests" / "aux" / "fast_div_check.hip"), "-o", str(exe)], check=True, timeout=600)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_fused_adam_host_side_contracts():
+    """FusedAdam's host logic that needs no GPU: the plain zero_grad (set_to_none) clears every .grad like
+    torch.optim.Optimizer.zero_grad, set_to_none=False keeps torch's behaviour; overlap_tail registers / leaves the
+    early-update hook of its Unet; the hparam reaches the optimiser from both LitModules (torch.optim.Adam stands at
+    d3f/train_denoiser/lit_module.py:95 and d3f/train_deep_fake/lit_module.py:116-120 in the reference)."""
+    import torch
+
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    net = Unet("resnet34", None, 3, 3, None)
+    opt = FusedAdam(net.parameters(), lr=1e-3, module=net)
+    assert not opt.overlap_tail and net._rt.get("early_update") is None
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.zero_grad(set_to_none=False)
+    assert all(p.grad is not None for p in net.parameters())
+    opt.zero_grad()
+    assert all(p.grad is None for p in net.parameters())
+    opt2 = FusedAdam(net.parameters(), lr=1e-3, module=net, overlap_tail=True)
+    assert opt2.overlap_tail and net._rt["early_update"] == opt2._early_update
+    with pytest.raises(NotImplementedError):
+        opt2.param_groups[0]["weight_decay"] = 0.1
+        opt2._hyper()
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    hp = dict(batch_size=2, learning_rate=0.02, max_epochs=1, cosine_scheduler_max_epoch=1, num_workers=0,
+              encoder_name="resnet34", noise_exponential_sampling_lambda=5, mean=[128] * 3, std=[128] * 3, synthetic=True,
+              image_size=64, augment=False)
+    (o,), _ = LitModule(**hp).configure_optimizers()
+    assert not o.overlap_tail
+    (o,), _ = LitModule(**dict(hp, optimizer_overlap_tail=True)).configure_optimizers()
+    assert o.overlap_tail
