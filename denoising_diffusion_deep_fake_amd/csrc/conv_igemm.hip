@@ -164,13 +164,14 @@ __device__ __forceinline__ void split3x4(const uint4& v, uint2& h, uint2& m, uin
 
 // -DD3F_PHASE_TIMING (profiling builds only, profiles/tools/phase_timing.py): thread 0 of every workgroup adds the
 // duration of its prologue / main loop / epilogue (100 MHz wall clock ticks) to d3f_phase_acc[0..2], [3] counts
-// workgroups, [4] sums whole-workgroup lifetimes.
+// workgroups, [4] sums whole-workgroup lifetimes, [5] the SHADER clock cycles (s_memtime) of the main loop: [5] / [1] x 100 MHz
+// is the clock the chip holds while the k-loop runs.
 #ifdef D3F_PHASE_TIMING
 __device__ unsigned long long d3f_phase_acc[8];
 struct PhaseTimer {
-  unsigned long long t0, t1, t2;
+  unsigned long long t0, t1, t2, c1, c2;
   bool on;
-  __device__ PhaseTimer() : t0(wall_clock64()), t1(0), t2(0), on(threadIdx.x == 0) {}
+  __device__ PhaseTimer() : t0(wall_clock64()), t1(0), t2(0), c1(0), c2(0), on(threadIdx.x == 0) {}
   __device__ ~PhaseTimer() {
     if (on) {
       const unsigned long long t3 = wall_clock64();
@@ -179,12 +180,13 @@ struct PhaseTimer {
       atomicAdd(&d3f_phase_acc[2], t3 - t2);
       atomicAdd(&d3f_phase_acc[3], 1ull);
       atomicAdd(&d3f_phase_acc[4], t3 - t0);
+      atomicAdd(&d3f_phase_acc[5], c2 - c1);
     }
   }
 };
 #define D3F_PHASE_BEGIN PhaseTimer phase_timer
-#define D3F_PHASE_LOOP phase_timer.t1 = wall_clock64()
-#define D3F_PHASE_EPILOGUE phase_timer.t2 = wall_clock64()
+#define D3F_PHASE_LOOP (phase_timer.t1 = wall_clock64(), phase_timer.c1 = __builtin_readcyclecounter())
+#define D3F_PHASE_EPILOGUE (phase_timer.c2 = __builtin_readcyclecounter(), phase_timer.t2 = wall_clock64())
 extern "C" int d3f_debug_phase_read(unsigned long long out[8], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d3f_phase_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {

@@ -30,7 +30,7 @@ shapes = {
 L = _lib.lib()
 L.d3f_debug_phase_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 8)()
-print(f"{'layer':20s} {'kernel us':>9s} {'wg':>6s} | per workgroup (us): prologue  loop  epilogue  lifetime")
+print(f"{'layer':20s} {'kernel us':>9s} {'wg':>6s} | per workgroup (us): prologue  loop  epilogue  lifetime | shader clock in the loop (MHz)")
 for name, (H, W, C0, C1, Co, k, st, pd, up) in shapes.items():
     d = ops.make_desc(B, H, W, C0, C1, Co, k, st, pd, up)
     h0, w0 = (H // 2, W // 2) if up else (H, W)
@@ -52,4 +52,5 @@ for name, (H, W, C0, C1, Co, k, st, pd, up) in shapes.items():
     L.d3f_debug_phase_read(buf, 1)
     wg = buf[3] / n
     t = [buf[i] / max(buf[3], 1) * 0.01 for i in (0, 1, 2, 4)]
-    print(f"{name:20s} {e0.elapsed_time(e1) / n * 1e3:9.1f} {wg:6.0f} | {t[0]:8.2f} {t[1]:8.2f} {t[2]:8.2f} {t[3]:8.2f}")
+    mhz = buf[5] / max(buf[1], 1) * 100.0  # shader cycles per 100 MHz tick of the loop phase
+    print(f"{name:20s} {e0.elapsed_time(e1) / n * 1e3:9.1f} {wg:6.0f} | {t[0]:8.2f} {t[1]:8.2f} {t[2]:8.2f} {t[3]:8.2f} | {mhz:6.0f}")
