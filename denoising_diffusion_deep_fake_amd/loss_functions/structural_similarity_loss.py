@@ -19,7 +19,7 @@ class _MseSsimFunction(torch.autograd.Function):
         out, grad = ops.mse_ssim_loss(prediction.detach(), target.detach(), lo, hi)
         ctx.save_for_backward(grad)
         ctx.parts = out  # {loss, mse, ssim} on device, for logging without extra kernels
-        return out[0].clone()
+        return out[0]  # a view of this call's own result buffer (no copy kernel on the step's dependent chain)
 
     @staticmethod
     def backward(ctx, grad_output):
