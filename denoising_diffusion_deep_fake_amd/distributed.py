@@ -58,30 +58,49 @@ def shared_seed(group=None):
 
 
 class BucketAllReducer:
-    """sum-all-reduce of gradient buckets, launched as they become ready, joined by wait()."""
+    """sum-all-reduce of gradient buckets, launched as they become ready, joined by wait().
 
-    def __init__(self, group=None, force=False):
+    compress="bf16" (opt-in): every bucket travels as bfloat16 -- 48.9 instead of 97.8 MB per net and step
+    over xGMI, whose ring all-reduce is bound per link.  The fp32 bucket is rounded into a staging buffer that lives until
+    wait(), summed there by the collective (bf16 sums, as torch DDP's bf16_compress_hook), and written back to the fp32
+    gradient in wait(); the conversions are stream-ordered torch copies (plumbing, no host sync).  Default: fp32, exact."""
+
+    def __init__(self, group=None, force=False, compress=None):
+        if compress not in (None, "bf16"):
+            raise ValueError(f"BucketAllReducer: compress must be None or 'bf16', got {compress!r}")
         self.group = group
         self.works = []
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force  # issue the collective even for one rank (exercises RCCL on a one-GPU box)
+        self.compress = compress
+        self._staging = {}   # segment -> bf16 buffer, reused every step
 
     def __call__(self, segment, flat_slice):
-        if self.world_size > 1 or self.force:
-            self.works.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if not (self.world_size > 1 or self.force):
+            return
+        if self.compress is None:
+            self.works.append((dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            return
+        buf = self._staging.get(segment)
+        if buf is None or buf.numel() != flat_slice.numel() or buf.device != flat_slice.device:
+            buf = self._staging[segment] = torch.empty(flat_slice.numel(), dtype=torch.bfloat16, device=flat_slice.device)
+        buf.copy_(flat_slice)  # on the caller's current stream (the engine's side stream): behind the bucket's gradients
+        self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, flat_slice))
 
     def wait(self):
-        for w in self.works:
+        for w, buf, dst in self.works:
             w.wait()
+            if buf is not None:
+                dst.copy_(buf)  # on the stream that called wait() (the optimiser's), behind the collective
         self.works = []
 
 
 class DataParallel:
     """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
 
-    def __init__(self, model, optimizer, group=None, sync_batchnorm=False):
+    def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None):
         self.model, self.optimizer = model, optimizer
-        self.reducer = BucketAllReducer(group)
+        self.reducer = BucketAllReducer(group, compress=grad_compress)
         self.world_size = self.reducer.world_size
         if self.world_size > 1 and sync_batchnorm:
             # pytorch_lightning's Trainer(sync_batchnorm=True): batch statistics over every rank's images

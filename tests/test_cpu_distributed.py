@@ -61,6 +61,44 @@ def test_bucket_allreduce_world2():
     assert ret[0][1] == [0, 1, 2, 3, 4] and ret[1][1] == [5, 6, 7, 8, 9]
 
 
+def _worker_bf16(rank, world, port, ranges, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer, init_process_group
+    init_process_group("gloo")
+    n = ranges[0][1]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    red = BucketAllReducer(compress="bf16")
+    for step in range(2):  # the staging buffers are reused from the second step on
+        flat.copy_(mine)
+        for seg, (b, e) in enumerate(ranges):
+            red(seg, flat[b:e])
+        red.wait()
+    # what every rank must hold: the bf16 sum of the bf16-rounded per-rank gradients
+    parts = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(world)]
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = acc + p
+    exact = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    ret[rank] = (bool(torch.equal(flat, acc.float())), float((flat - exact).norm() / exact.norm()), len(red._staging))
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_bf16_compression_world2():
+    """opt-in bf16 gradient buckets: both ranks end with the same values -- the bf16 sum of the rounded
+    per-rank buckets, written back into the fp32 gradient -- within bf16 rounding of the exact sum"""
+    world = 2
+    ranges = [(700, 1000), (400, 700), (150, 400), (0, 150)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_worker_bf16, (world, _free_port(), ranges, ret), world, seconds=90)
+    for r in range(world):
+        ok, err, nbuf = ret[r]
+        assert ok and err < 8e-3 and nbuf == len(ranges), ret[r]
+
+
 def test_bucket_allreduce_world4_ragged_shards():
     """four ranks (the driver's N=4 point, rehearsed over gloo): same reduction, uneven shards of 10 items"""
     world = 4
