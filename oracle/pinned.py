@@ -91,3 +91,52 @@ def pinned_backward(ref, x, grad_out, activations, names):
     dact = {n: a.grad for n, a in zip(names, acts) if a.grad is not None}
     grads = {k: p.grad for k, p in pinned.named_parameters()}
     return out.detach(), dact, grads
+
+
+class TeacherForcedReLU(nn.Module):
+    """ReLU of the teacher-forced BACKWARD gate: forward value = the other run's activation (so the next layer sees that
+    run's operand), gradient path = x * mask with the mask pinned to that activation, and the gradient arriving at the
+    output -- the oracle's own sum over this activation's consumers -- is RECORDED and then REPLACED by the other run's
+    gradient, so that every comparison downstream sees one layer's backward arithmetic only."""
+
+    def __init__(self, acts, grads_in, recorded):
+        super().__init__()
+        self.acts, self.grads_in, self.recorded = acts, grads_in, recorded
+
+    def forward(self, x):
+        a = self.acts.pop(0).to(x.dtype)
+        forced = self.grads_in.pop(0)
+        lin = x * (a > 0).to(x.dtype)
+        out = lin + (a - lin).detach()
+        slot = {}
+        self.recorded.append(slot)
+
+        def swap(g, slot=slot, forced=forced):
+            slot["g"] = g.detach().clone()
+            return forced.to(g.dtype)
+
+        out.register_hook(swap)
+        return out
+
+
+def teacher_forced_backward(ref, x, grad_out, activations, act_grads, names):
+    """float64 copy of `ref` (train mode) with BOTH passes teacher-forced by another run: in front of every layer the
+    forward is handed that run's activation (`activations[unit]`), ReLU / max-pool decisions are pinned to it, and in
+    the backward pass the gradient w.r.t. every unit's activation is replaced by that run's (`act_grads[unit]`) after the
+    oracle's own value was recorded.  Each recorded activation gradient and each parameter gradient is therefore ONE
+    layer's data gradient + BatchNorm backward + weight gradient applied to the other run's operands (a block's
+    downsample branch: two layers).  Returns ({unit: oracle d loss / d activation}, {parameter name: gradient});
+    restates autograd through d3f/train_denoiser/lit_module.py:117-119 for the bf16 engine plan."""
+    model = copy.deepcopy(ref).double().train()
+    acts = [activations[n] for n in names]
+    gin = [act_grads[n] for n in names]
+    recorded = []
+    swap_relus(model, lambda: TeacherForcedReLU(acts, gin, recorded))
+    _, idx = F.max_pool2d(activations["encoder.conv1"].float(), 3, 2, 1, return_indices=True)
+    model.encoder.maxpool = PinnedMaxPool(idx)
+    out = model(x.double())
+    assert not acts and not gin and len(recorded) == len(names)
+    out.backward(grad_out.double())
+    dact = {n: slot["g"] for n, slot in zip(names, recorded) if "g" in slot}
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    return dact, grads

@@ -203,3 +203,73 @@ def test_bf16_every_layer_teacher_forced(shape):
         assert e < 5.5e-3, ("a", n, e)
         worst_a = max(worst_a, e)
     print(f"bf16 teacher-forced {shape}: worst conv output {worst_y:.2e}, worst activation {worst_a:.2e}")
+
+
+# gates of the teacher-forced BACKWARD test = measured on MI355X x 1.5 (see the docstring)
+BF16_BWD_TOL_DA = 1.0e-2
+BF16_BWD_TOL_W = 1.0e-2
+BF16_BWD_TOL_BN = 1.0e-2
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shape", [(4, 64, 64), (16, 128, 128), (16, 256, 256)],
+                         ids=["4x64x64", "config1_16x128x128", "headline_16x256x256"])
+def test_bf16_every_layer_backward_teacher_forced(shape):
+    """The bf16 engine plan's BACKWARD pass tensor by tensor (it differs from the fp32 plan: 64x32 k-split tiles, bf16
+    split-K, half-vector stem weight gradient, bf16 `bn_fused` backward, no Winograd, no fp32 `conv_patch`).  The float64
+    oracle is teacher-forced in BOTH directions (oracle/pinned.py:teacher_forced_backward): the forward sees the HIP run's
+    bf16 activation in front of every layer with ReLU / max-pool decisions pinned to it, and the gradient arriving at
+    every unit's activation is replaced by the HIP run's exported ":da" after the oracle's own value was recorded.  Every
+    ":da" and each of the 143 parameter gradients therefore compares ONE layer's data gradient + BatchNorm backward +
+    weight gradient on identical operands: what is left is bf16 rounding of the stored dy / y / packed weights
+    (2^-9 per element).  A missed accumulate, a wrong bucket edge, tap or slab is O(1e-1 .. 1).
+    Replaces autograd through /root/reference/d3f/train_denoiser/lit_module.py:117-119 in the bf16 mode (BASELINE configs[2])."""
+    import gc
+
+    import oracle
+    from oracle.pinned import teacher_forced_backward, unit_names
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    B, H, W = shape
+    torch.manual_seed(3)
+    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+        ref.segmentation_head[0].bias.normal_(0, 0.1)
+    net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16")
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().train()
+    x = oracle.synthetic_face_crops(B, (H, W), seed=21)
+    pred = net(x.cuda())
+    _, gout = ops.mse_ssim_loss(pred.detach(), oracle.synthetic_face_crops(B, (H, W), seed=22).cuda())
+    pred.backward(gout)
+    names = unit_names()
+    chan = {n: dict(ref.named_modules())[n].out_channels for n in names}
+    hip_a = {n: net.export_activation(n + ":a").cpu()[:, :chan[n]] for n in names}
+    hip_da = {n: net.export_activation(n + ":da").cpu()[:, :chan[n]] for n in names}
+    hip_grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    gout = gout.cpu()
+    del net, pred
+    torch.cuda.empty_cache()
+    gc.collect()
+    dact, grads = teacher_forced_backward(ref, x, gout, hip_a, hip_da, names)
+    assert set(dact) == set(names) and set(grads) == set(hip_grads)
+    worst = {"da": ("", 0.0), "w": ("", 0.0), "bn": ("", 0.0)}
+    bad = []
+    for n in names:
+        e = rel_l2(hip_da[n], dact[n])
+        worst["da"] = max(worst["da"], (n, e), key=lambda t: t[1])
+        if not e < BF16_BWD_TOL_DA:
+            bad.append(("da", n, e))
+    for k, g in grads.items():
+        e = rel_l2(hip_grads[k], g)
+        kind = "w" if g.dim() == 4 else "bn"
+        worst[kind] = max(worst[kind], (k, e), key=lambda t: t[1])
+        if not e < (BF16_BWD_TOL_W if kind == "w" else BF16_BWD_TOL_BN):
+            bad.append((kind, k, e))
+    print(f"bf16 teacher-forced backward {shape}: worst activation gradient {worst['da'][1]:.2e} ({worst['da'][0]}), "
+          f"worst conv weight gradient {worst['w'][1]:.2e} ({worst['w'][0]}), worst BatchNorm / bias gradient "
+          f"{worst['bn'][1]:.2e} ({worst['bn'][0]})")
+    assert not bad, bad

@@ -132,6 +132,13 @@ def test_every_layer_at_the_headline_configuration(shape):
     _layer_parity("f32", *shape)
 
 
+@pytest.mark.timeout(1500)
+def test_every_layer_at_the_headline_configuration_f32x3():
+    """the exact 3-way bf16 split mode (compute_dtype="f32x3") under the same two gates at the headline plan (its engine
+    plan keeps split-K + slab reduce where fp32-MFMA uses the in-workgroup k-split)"""
+    _layer_parity("f32x3", 16, 256, 256)
+
+
 @pytest.mark.timeout(900)
 def test_eval_forward_b64_256_against_oracle():
     """BASELINE configs[4]'s shape: one eval-mode forward (BatchNorm running statistics folded into the conv
