@@ -205,10 +205,14 @@ def test_bf16_every_layer_teacher_forced(shape):
     print(f"bf16 teacher-forced {shape}: worst conv output {worst_y:.2e}, worst activation {worst_a:.2e}")
 
 
-# gates of the teacher-forced BACKWARD test = measured on MI355X x 1.5 (see the docstring)
-BF16_BWD_TOL_DA = 1.0e-2
-BF16_BWD_TOL_W = 1.0e-2
-BF16_BWD_TOL_BN = 1.0e-2
+# gates of the teacher-forced BACKWARD test = measured on MI355X x 1.5 (gpurun_out/r05_a, worst tensor per class at
+# 4x64x64 / 16x128x128 / 16x256x256): activation gradients 3.79 / 3.84 / 3.86e-3 (decoder.blocks.4.conv1.0); conv weight
+# gradients 4.56 / 5.27 / 8.92e-3 (encoder.layer1.1.conv1.weight: a sum over 65 536 pixels of products whose dy factor
+# carries 2^-9 of bf16 rounding -- the sum itself cancels to ~1/8 of its terms' root-sum-square at this batch, so the
+# RELATIVE error grows with the pixel count); BatchNorm affine / bias gradients 5.09 / 4.22 / 4.47e-3
+BF16_BWD_TOL_DA = 5.8e-3
+BF16_BWD_TOL_W = 1.35e-2
+BF16_BWD_TOL_BN = 7.7e-3
 
 
 @pytest.mark.timeout(1500)
