@@ -51,6 +51,12 @@ def parse():
                          "Bit-identical to the eager step, and SLOWER on this ROCm (measured r03: bf16 4.6 -> 10.9 ms, "
                          "128x128 3.8 -> 11.5 ms per step: a replayed graph whose nodes span three captured streams costs "
                          "~30 us per node; captured on one stream it equals the eager single-stream step) -- off by default")
+    ap.add_argument("--dp-buckets", type=int, default=4, choices=[1, 2, 4],
+                    help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 4 = one per "
+                         "engine segment (default), 2 = (head .. layer4) | (layer3 .. stem), 1 = one all-reduce at the end")
+    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "180")),
+                    help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
+                         "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N=1: price the data-parallel machinery on ONE GPU -- the same step plain and with the 4 gradient "
                          "buckets all-reduced over a single-rank RCCL group (BucketAllReducer(force=True)); one JSON line")
@@ -313,9 +319,9 @@ def dp_selftest(args):
     nb = 4
     data = [synthetic_face_crops(args.batch, args.size, seed=1234 + i, device=dev) for i in range(nb)]
 
-    def mode(bucketed):
-        lit.model.set_grad_sync(red if bucketed else None)
-        opt.before_step = red.wait if bucketed else None
+    def mode(buckets):  # None: the plain pass; 4 / 2 / 1: that many exchange buckets over the single-rank RCCL group
+        lit.model.set_grad_sync(red if buckets else None, buckets)
+        opt.before_step = red.wait if buckets else None
 
     def step(i):
         opt.zero_grad(set_to_none=True)
@@ -324,40 +330,43 @@ def dp_selftest(args):
         opt.step()
         return loss
 
-    def grads_of(bucketed):  # one backward on a fixed batch and fixed noise, no optimiser step
-        mode(bucketed)
+    def grads_of(buckets):  # one backward on a fixed batch and fixed noise, no optimiser step
+        mode(buckets)
         opt.zero_grad(set_to_none=True)
         torch.manual_seed(99)
         lit.training_step({"image": data[0], "index": None}, 0).backward()
-        if bucketed:
+        if buckets:
             red.wait()
         torch.cuda.synchronize()
         return lit.model.flat_grads.clone()
 
+    variants = (None, 4, 2, 1)
     for i in range(args.warmup):
-        mode(i % 2 == 1)
+        mode(variants[i % len(variants)])
         step(i)
-    identical = bool(torch.equal(grads_of(False), grads_of(True)))
-    rounds, times = 3, {False: [], True: []}
+    g_plain = grads_of(None)
+    identical = all(bool(torch.equal(g_plain, grads_of(b))) for b in variants[1:])
+    rounds, times = 3, {b: [] for b in variants}
     for r in range(rounds):
-        for bucketed in (False, True):
-            mode(bucketed)
+        for b in variants:
+            mode(b)
             step(0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 loss = step(i)
             torch.cuda.synchronize()
-            times[bucketed].append(1e3 * (time.perf_counter() - t0) / args.steps)
-            log(f"dp-selftest round {r} {'bucketed+RCCL' if bucketed else 'plain'}: {times[bucketed][-1]:.3f} ms/step")
-    plain, buck = min(times[False]), min(times[True])
+            times[b].append(1e3 * (time.perf_counter() - t0) / args.steps)
+            log(f"dp-selftest round {r} {str(b) + ' buckets + RCCL' if b else 'plain'}: {times[b][-1]:.3f} ms/step")
+    plain, buck = min(times[None]), min(times[4])
     segs = lit.model._rt["last_engine"].seg_ranges
-    res = {"workload": f"dp-selftest: d3f train_denoiser step at N=1, plain vs 4 gradient buckets all-reduced over a "
+    res = {"workload": f"dp-selftest: d3f train_denoiser step at N=1, plain vs 4 / 2 / 1 gradient buckets all-reduced over a "
                        f"single-rank RCCL group, {args.size}x{args.size}, bs={args.batch}, {args.dtype}",
            "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "steps": args.steps, "rounds": rounds,
            "ms_per_step_plain": round(plain, 3), "ms_per_step_bucketed_rccl": round(buck, 3),
-           "dp_tax": round(buck / plain - 1.0, 4), "all_rounds_ms": {"plain": [round(t, 3) for t in times[False]],
-                                                                     "bucketed_rccl": [round(t, 3) for t in times[True]]},
+           "dp_tax": round(buck / plain - 1.0, 4),
+           "dp_tax_by_buckets": {str(b): round(min(times[b]) / plain - 1.0, 4) for b in variants[1:]},
+           "all_rounds_ms": {("plain" if b is None else f"buckets{b}"): [round(t, 3) for t in times[b]] for b in variants},
            "bucket_mb": [round(4e-6 * (e - b), 1) for b, e in segs],
            "gradients_bit_identical_to_plain": identical, "final_loss": round(float(loss.item()), 5),
            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")}}
@@ -427,7 +436,30 @@ def main():
     import ctypes as C
     import torch.distributed as dist
 
-    world, rank, local = init_process_group()
+    # N > 1 must never hang the driver's scaling run: a watchdog thread ends THIS rank with a non-zero code, its rank and
+    # the stage it is stuck in (os._exit -- no exec, no retry; torch.distributed.run then tears the other ranks down)
+    # if the rendezvous + first barrier take longer than --dist-timeout; the process group carries the same timeout for
+    # every later collective (RCCL's watchdog raises with the failing collective's name).
+    stage = {"name": "rendezvous (init_process_group)"}
+    watchdog = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import threading
+
+        def _stuck():
+            sys.stderr.write(f"[bench] rank {os.environ.get('RANK')} (local {os.environ.get('LOCAL_RANK')}): no progress "
+                             f"for {args.dist_timeout:.0f} s in stage '{stage['name']}' (MASTER {os.environ.get('MASTER_ADDR')}:"
+                             f"{os.environ.get('MASTER_PORT')}, backend {os.environ.get('D3F_DIST_BACKEND') or 'nccl=RCCL'}); "
+                             f"giving up instead of hanging\n")
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(args.dist_timeout, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        world, rank, local = init_process_group(timeout_s=args.dist_timeout)
+    except Exception as e:  # RCCL / gloo rendezvous errors: say which rank, then fail
+        sys.stderr.write(f"[bench] rank {os.environ.get('RANK')}: init_process_group failed: {type(e).__name__}: {e}\n")
+        raise
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("D3F_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (gloo)
@@ -443,7 +475,14 @@ def main():
                     optimizer_overlap_tail=args.overlap_tail == "on").to(dev).train()
     (opt,), _ = lit.configure_optimizers()
     lit.attach_optimizers([opt])
-    DataParallel(lit.model, opt)
+    stage["name"] = "parameter broadcast (DataParallel)"
+    DataParallel(lit.model, opt, buckets=args.dp_buckets)
+    if world > 1:
+        stage["name"] = "first barrier"
+        dist.barrier()
+        torch.cuda.synchronize()
+    if watchdog is not None:
+        watchdog.cancel()
     torch.manual_seed(1000 + rank)  # distinct noise stream per rank
     nb = 4  # resident synthetic batches, distinct per rank
     data = [synthetic_face_crops(args.batch, args.size, seed=1234 + 97 * rank + i, device=dev) for i in range(nb)]
@@ -503,8 +542,16 @@ def main():
         L.d3f_profile_enable(0)
     lossv = float(loss.item())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    replicas_identical = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # every rank applied the same summed gradients to the same broadcast parameters: the replicas must agree BIT FOR
+        # BIT after the run (an integer checksum of the parameter bits, min == max over ranks)
+        cs = lit.model.flat_params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool((lo == hi).item())
     dt = float(tmax.item())
     if rank != 0:
         if world > 1:
@@ -532,7 +579,13 @@ def main():
                    "graph_step": not lit.automatic_optimization,
                    # True: Adam over every gradient bucket but the last ran inside backward (FusedAdam(overlap_tail=True));
                    # False at N > 1 (the reducer keeps the whole update in step()) and under --overlap-tail off
-                   "adam_overlap_tail": bool(opt.overlap_tail and world == 1 and lit.automatic_optimization),
+                   # (counted, not inferred: steps whose early update really ran -- a reducer, a missing side stream or
+                   # gradients outside the flat buffer switch it off silently)
+                   "adam_overlap_tail": bool(opt.early_updates > 0),
+                   "adam_overlap_tail_steps": int(opt.early_updates),
+                   # N > 1: gradient exchange buckets per backward pass; parameter bits equal on every rank after the run
+                   "dp_buckets": args.dp_buckets if world > 1 else None,
+                   "replicas_bit_identical": replicas_identical,
                    # what the collective layer saw (None at N=1: no process group, no exchange step)
                    "backend": dist.get_backend() if world > 1 else None,
                    "ranks_seen": dist.get_world_size() if world > 1 else 1,
@@ -598,6 +651,8 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if replicas_identical is False:
+        raise SystemExit("the replicas' parameters differ after the run: the gradient exchange is broken")
 
 
 if __name__ == "__main__":

@@ -100,6 +100,8 @@ void adam_coefficients(float lr, float beta1, float beta2, float eps, int step, 
 int adam_step_dev_launch(float* p, const float* g, float* m, float* v, long n, const float* coef_dev,
                          hipStream_t stream) {
   if (n == 0) return 0;
+  D3F_CHECK((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+            "adam: params / grads / exp_avg / exp_avg_sq must be 16-byte aligned (slice offsets: multiples of 4 floats)");
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
@@ -112,6 +114,9 @@ int adam_step_launch(float* p, const float* g, float* m, float* v, long n, float
                      float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
   D3F_CHECK(step >= 1, "adam: step counts from 1");
   if (n == 0) return 0;
+  // the kernel streams 16-byte vectors: a slice of the flat buffers (per-bucket updates) must start on a vector boundary
+  D3F_CHECK((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+            "adam: params / grads / exp_avg / exp_avg_sq must be 16-byte aligned (slice offsets: multiples of 4 floats)");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);

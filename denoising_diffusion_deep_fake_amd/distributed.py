@@ -22,9 +22,14 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, timeout_s=None):
+    """timeout_s (default D3F_DIST_TIMEOUT or 180): the process group's collective timeout -- a rank that never shows up
+    at the rendezvous or a collective that never completes raises on the others instead of hanging the job."""
     world, rank, local = env_world()
     if world > 1 and not dist.is_initialized():
+        import datetime
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("D3F_DIST_TIMEOUT", "180"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -33,7 +38,8 @@ def init_process_group(backend=None):
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
     return world, rank, local
 
 
@@ -98,8 +104,12 @@ class BucketAllReducer:
 class DataParallel:
     """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
 
-    def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None):
+    def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None, buckets=None):
+        """buckets: exchange buckets per backward pass (None = 4, one per engine segment; 2; 1; or explicit segment ranges --
+        Unet.set_grad_sync).  4 starts the first all-reduce earliest and leaves 5.4 MB behind the backward pass; every
+        bucket costs the dependent chain a cross-stream event pair (bench.py --dp-selftest prices both on one GPU)."""
         self.model, self.optimizer = model, optimizer
+        self.buckets = buckets
         self.reducer = BucketAllReducer(group, compress=grad_compress)
         self.world_size = self.reducer.world_size
         if self.world_size > 1 and sync_batchnorm:
@@ -110,7 +120,7 @@ class DataParallel:
             dist.broadcast(model.flat_params, src=0, group=group)
             dist.broadcast(model.flat_bn_stats, src=0, group=group)
             model.mark_params_changed()
-            model.set_grad_sync(self.reducer)
+            model.set_grad_sync(self.reducer, buckets)
             optimizer.grad_scale = 1.0 / self.world_size
             optimizer.before_step = self.reducer.wait
 

@@ -24,7 +24,10 @@ class FusedAdam(torch.optim.Optimizer):
         the caller accepts with it: every backward() is followed by exactly one step() with unchanged lr / betas / eps
         (Lightning's automatic optimisation, this package's Trainer and bench.py do that); the parameters of layer3,
         layer4, the decoder and the head already hold their updated values when backward() returns; .grad is complete
-        and untouched as always.  A data-parallel reducer, or gradients that do not land in the flat buffer directly
+        and untouched as always -- but EDITING .grad between backward() and step() (clip_grad_norm_ / Lightning's
+        gradient_clip_val, GradScaler.unscale_, hooks that rescale gradients) cannot reach the 94 % of the parameters
+        whose update already ran: step() detects in-place edits of the flat gradient buffer (its version counter) and
+        RAISES instead of applying them to the last bucket only; use overlap_tail=False with any such step.  A data-parallel reducer, or gradients that do not land in the flat buffer directly
         (.grad not None before backward: zero_grad(set_to_none=False)), switch the early part off by themselves (the
         whole update then runs in step() as without the flag); a second backward() before step() (gradient accumulation),
         changed hyper-parameters or cleared gradients between backward() and step() raise in step()."""
@@ -46,8 +49,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = None
         self.overlap_tail = bool(overlap_tail)
         self._early = None  # (lo, hi, hyper-parameters, gradient buffer) of an update already applied inside backward
-        if self.overlap_tail:
-            module.set_early_update(self._early_update)
+        self.early_updates = 0  # steps whose leading buckets were really updated inside backward (what bench.py reports)
+        # always (re)set the module's hook: a FusedAdam built earlier for the same module with overlap_tail=True must
+        # not keep updating [lo, hi) with ITS moments inside backward next to this optimiser's step()
+        module.set_early_update(self._early_update if self.overlap_tail else None)
 
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad; the set_to_none form without its per-parameter bookkeeping (143 parameters:
@@ -74,9 +79,12 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
         hyper = self._hyper()
+        if lo % 4 or hi % 4:
+            raise RuntimeError(f"FusedAdam(overlap_tail=True): bucket range [{lo}, {hi}) is not on 16-byte boundaries")
         ops.adam_step(flat[lo:hi], grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], hyper[0], hyper[1], hyper[2],
                       hyper[3], self._step + 1, hyper[4])
-        self._early = (lo, hi, hyper, grads.data_ptr(), self.module._rt.get("backward_calls", 0))
+        self._early = (lo, hi, hyper, grads.data_ptr(), self.module._rt.get("backward_calls", 0), grads._version)
+        self.early_updates += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -112,7 +120,12 @@ class FusedAdam(torch.optim.Optimizer):
         if early is None:
             ranges = [(0, flat.numel())]
         else:
-            lo, hi, used, gptr, calls = early
+            lo, hi, used, gptr, calls, gver = early
+            if grads._version != gver:
+                raise RuntimeError("FusedAdam(overlap_tail=True): the gradients were modified in place between backward() "
+                                   "and step() (gradient clipping, GradScaler.unscale_, a hook that rescales .grad?), but "
+                                   "the update of layer3 / layer4 / decoder / head already ran inside backward() with the "
+                                   "unmodified values; build the optimiser with overlap_tail=False for such steps")
             if calls != m._rt.get("backward_calls", 0):
                 raise RuntimeError("FusedAdam(overlap_tail=True): another backward() ran before step(), but part of this "
                                    "step's update already ran inside the first one (gradient accumulation needs "

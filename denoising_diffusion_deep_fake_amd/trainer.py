@@ -212,7 +212,8 @@ def optimizer_steps(model, optimizers, opt_params, batch, batch_idx, takes_idx, 
 class Trainer:
     def __init__(self, max_epochs=1, max_steps=-1, callbacks=None, log_every_n_steps=50, gpus=None,
                  accelerator=None, devices=None, default_root_dir="lightning_logs", flush_every=100,
-                 enable_checkpointing=True, limit_train_batches=None, limit_val_batches=None, sync_batchnorm=False):
+                 enable_checkpointing=True, limit_train_batches=None, limit_val_batches=None, sync_batchnorm=False,
+                 grad_buckets=None, grad_compress=None):
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.callbacks = list(callbacks or [])
         self.log_every_n_steps = log_every_n_steps
@@ -222,6 +223,9 @@ class Trainer:
         self.limit_train_batches = limit_train_batches
         self.limit_val_batches = limit_val_batches
         self.sync_batchnorm = sync_batchnorm  # Lightning's flag: BatchNorm statistics over all ranks (default: per GPU)
+        # data parallel only (no Lightning counterpart; distributed.DataParallel): exchange buckets per backward pass
+        # (None = 4) and "bf16" to send the gradient buckets as bfloat16 over xGMI
+        self.grad_buckets, self.grad_compress = grad_buckets, grad_compress
         self.global_step = 0
         self.current_epoch = 0
         self.logger = None
@@ -350,7 +354,8 @@ class Trainer:
         for opt in self.optimizers:
             mod = getattr(opt, "module", None)
             if mod is not None:
-                dist_utils.DataParallel(mod, opt, sync_batchnorm=self.sync_batchnorm)
+                dist_utils.DataParallel(mod, opt, sync_batchnorm=self.sync_batchnorm, buckets=self.grad_buckets,
+                                        grad_compress=self.grad_compress)
         takes_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
         # independent optimizer steps on their own streams (the module decides: LitModule.optimizer_streams)

@@ -387,10 +387,33 @@ class Unet(nn.Module):
             for eng in pool:
                 eng.set_bn_sync(*(self._rt["bn_sync"] or (None, 1)))
 
-    def set_grad_sync(self, fn):
-        """fn(segment_index, flat_grad_slice) is called as soon as a gradient bucket is final
-        (data-parallel all-reduce overlap); None disables."""
+    def set_grad_sync(self, fn, buckets=None):
+        """fn(bucket_index, flat_grad_slice) is called as soon as a gradient bucket is final
+        (data-parallel all-reduce overlap); None disables.
+
+        buckets: how the engine's backward segments (4: head + decoder | layer4 | layer3 | layer2 .. stem, final in that
+        order) are grouped into exchange buckets -- None / 4: one bucket per segment; 2: (head .. layer4) | (layer3 .. stem);
+        1: one bucket = the whole gradient at the end of backward; or an explicit list of (first, end) segment ranges
+        that tile range(nseg) in order.  Every bucket costs the chain a cross-stream event pair and RCCL a launch; fewer
+        buckets expose more of the LAST bucket's all-reduce behind the backward pass."""
         self._rt["grad_sync"] = fn
+        self._rt["grad_buckets"] = buckets
+
+    @staticmethod
+    def _bucket_groups(buckets, nseg):
+        if buckets is None or buckets == nseg:
+            return [(s, s + 1) for s in range(nseg)]
+        if isinstance(buckets, int):
+            if buckets == 1:
+                return [(0, nseg)]
+            if buckets == 2 and nseg >= 2:
+                return [(0, nseg // 2), (nseg // 2, nseg)]
+            raise D3FError(f"gradient buckets: {buckets} (the engine has {nseg} backward segments: 1, 2 or {nseg})")
+        groups = [(int(b), int(e)) for b, e in buckets]
+        if not groups or groups[0][0] != 0 or groups[-1][1] != nseg or any(b >= e for b, e in groups) or \
+                any(groups[i][1] != groups[i + 1][0] for i in range(len(groups) - 1)):
+            raise D3FError(f"gradient buckets {groups} do not tile the engine's {nseg} backward segments in order")
+        return groups
 
     def set_early_update(self, fn):
         """fn(flat_grad, lo, hi) is called INSIDE backward, on the caller's stream behind the chain's last kernel and a
@@ -490,15 +513,17 @@ class Unet(nn.Module):
             # (the dependent BatchNorm-backward -> data-gradient chain, the critical path) goes straight on with bucket
             # k+1; one join after the last bucket orders the optimiser behind the weight gradients.
             side = eng.side_stream(grad_out.device)
-            for s in range(eng.nseg):
+            for k, (s0, s1) in enumerate(self._bucket_groups(rt.get("grad_buckets"), eng.nseg)):
                 check(L.d3f_unet_backward_nojoin(eng.h, ptr(rt["flat"]), ptr(grad_out), ptr(target),
-                                                 ptr(eng.workspace), s, s + 1, stream_ptr()))
-                b, e = eng.seg_ranges[s]
+                                                 ptr(eng.workspace), s0, s1, stream_ptr()))
+                b, e = min(r[0] for r in eng.seg_ranges[s0:s1]), max(r[1] for r in eng.seg_ranges[s0:s1])
+                if sum(r[1] - r[0] for r in eng.seg_ranges[s0:s1]) != e - b:
+                    raise D3FError(f"gradient bucket {k}: segments {s0}..{s1 - 1} are not one contiguous flat range")
                 if side is None:  # D3F_SERIAL_BACKWARD: everything is on this stream
-                    sync(s, target[b:e])
+                    sync(k, target[b:e])
                 else:
                     with torch.cuda.stream(side):
-                        sync(s, target[b:e])
+                        sync(k, target[b:e])
             check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
         ptable = self._table()[0]
         if direct:

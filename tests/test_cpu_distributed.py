@@ -197,3 +197,56 @@ def test_shared_seed_prefers_pl_global_seed(monkeypatch):
     from denoising_diffusion_deep_fake_amd.distributed import shared_seed
     monkeypatch.setenv("PL_GLOBAL_SEED", "1234")
     assert shared_seed() == 1234
+
+
+def test_bucket_allreduce_world8_with_seed_agreement_and_shards():
+    """The rank-count-dependent pieces at the world size of the driver's scaling run (8 ranks over gloo; the GPU box's
+    process guard allows at most 6 processes on its card, so the 8-rank rehearsal is this CPU one plus the 4-ranks-on-one-
+    GPU bench rehearsal in tests/test_gpu_distributed.py): bucketed all-reduce with 8 peers, contiguous shards that tile
+    the data exactly, and one sampler seed on all ranks."""
+    world = 8
+    ranges = [(700, 1000), (400, 700), (150, 400), (0, 150)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_worker, (world, _free_port(), ranges, ret), world, seconds=150)
+    assert all(ret[r][0] for r in range(world))
+    got = sorted(i for r in range(world) for i in ret[r][1])
+    assert got == list(range(10))
+    seeds = mgr.dict()
+    _spawn_with_deadline(_seed_worker, (world, _free_port(), seeds), world, seconds=150)
+    assert len({seeds[r][1] for r in range(world)}) == 1 and seeds[0][1] == seeds[0][0]   # rank 0's seed, everywhere
+    idx = [i for r in range(world) for i in seeds[r][2]]
+    assert set(idx) == set(range(11)) and len(idx) == 16   # 11 images over 8 ranks: ceil -> 2 each, wrap-around padding
+
+
+def test_gradient_bucket_groups():
+    """Unet.set_grad_sync(fn, buckets): the grouping of the engine's 4 backward segments into exchange buckets."""
+    import pytest
+    from denoising_diffusion_deep_fake_amd import Unet
+    from denoising_diffusion_deep_fake_amd._lib import D3FError
+    g = Unet._bucket_groups
+    assert g(None, 4) == [(0, 1), (1, 2), (2, 3), (3, 4)] == g(4, 4)
+    assert g(2, 4) == [(0, 2), (2, 4)]
+    assert g(1, 4) == [(0, 4)]
+    assert g([(0, 3), (3, 4)], 4) == [(0, 3), (3, 4)]
+    for bad in (3, [(0, 2)], [(0, 2), (3, 4)], [(1, 4)], [(0, 2), (2, 2), (2, 4)]):
+        with pytest.raises(D3FError):
+            g(bad, 4)
+
+
+def test_bench_rank_without_peers_exits_instead_of_hanging():
+    """bench.py --gpus 2 as ONE rank of a job whose other rank never shows up (a dead peer in the driver's scaling run):
+    the rank must end non-zero within --dist-timeout, naming itself -- never hang."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), D3F_DIST_BACKEND="gloo")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-timeout", "6", "--steps", "1",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120, cwd=root)
+    assert out.returncode != 0
+    assert time.monotonic() - t0 < 90
+    assert "rank 1" in out.stderr, out.stderr[-1500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

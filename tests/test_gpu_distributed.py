@@ -278,3 +278,65 @@ def test_sync_batchnorm_two_ranks_equal_one_process():
         # that level, and an order of magnitude below what per-GPU statistics give on the same halves
         assert o["grad"] < 1e-2 and o["worst"] < 3e-2, o
         assert o["pred_unsynced"] > 1e-2 and o["grad_unsynced"] > 10 * o["grad"], o
+
+
+def test_bench_self_launch_four_ranks_replicas_identical():
+    """The driver's scaling run (`python bench.py --gpus N`, no launcher) rehearsed at the largest rank count the GPU
+    box's process guard allows next to this pytest process (at most 6 processes on the card: 4 ranks + pytest; the
+    8-PEER exchange, shard and seed arithmetic runs over gloo in tests/test_cpu_distributed.py): four ranks sharing the
+    one MI355X over gloo -- rendezvous inside --dist-timeout, parameter broadcast, 4 buckets x 4 peers per step, rank-0
+    JSON relay -- one JSON line, every rank seen, and the replicas' parameter BITS equal after the timed steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for buckets in (4, 2):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--batch", "4",
+               "--size", "64", "--dp-buckets", str(buckets), "--dist-timeout", "120"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        res = json.loads(lines[0])
+        cfg = res["config"]
+        assert res["n_gpus"] == 4 and cfg["ranks_seen"] == 4 and cfg["global_batch"] == 16 and cfg["parallelism"] == "dp4"
+        assert cfg["dp_buckets"] == buckets and cfg["replicas_bit_identical"] is True
+        assert res["value"] > 0 and res["scaling"] == "weak"
+
+
+def test_gradient_bucket_groupings_cover_the_flat_gradient_and_change_nothing():
+    """Unet.set_grad_sync(fn, buckets = 4 | 2 | 1 | explicit ranges): the hook fires once per bucket, back to front, the
+    slices tile the flat gradient exactly once, and the gradients are bit-identical to the plain (un-hooked) pass."""
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    torch.manual_seed(4)
+    net = Unet("resnet34", None, 3, 3, None).cuda().train()
+    x = synthetic_face_crops(2, 64, seed=70, device="cuda")
+    tgt = synthetic_face_crops(2, 64, seed=71, device="cuda")
+
+    def run(buckets, hooked=True):
+        calls = []
+        net.set_grad_sync((lambda k, sl: calls.append((k, sl.data_ptr(), sl.numel()))) if hooked else None, buckets)
+        for p in net.parameters():
+            p.grad = None
+        pred = net(x)
+        _, g = ops.mse_ssim_loss(pred.detach(), tgt)
+        pred.backward(g)
+        torch.cuda.synchronize()
+        return net.flat_grads.clone(), calls
+
+    plain, _ = run(None, hooked=False)
+    n, base = plain.numel(), None
+    for buckets, want in ((None, 4), (4, 4), (2, 2), (1, 1), ([(0, 3), (3, 4)], 2)):
+        got, calls = run(buckets)
+        assert torch.equal(got, plain), buckets
+        assert [c[0] for c in calls] == list(range(want)), (buckets, calls)
+        assert sum(c[2] for c in calls) == n
+        base = net.flat_grads.data_ptr()
+        spans = sorted((c[1], c[1] + 4 * c[2]) for c in calls)
+        assert spans[0][0] == base and spans[-1][1] == base + 4 * n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert all(calls[i][1] > calls[i + 1][1] for i in range(len(calls) - 1))   # back to front
+    net.set_grad_sync(None)
