@@ -42,7 +42,19 @@ def parse():
     ap.add_argument("--overlap-tail", default="off", choices=["on", "off"],
                     help="FusedAdam(overlap_tail=...): Adam over every gradient bucket but the last inside backward (single "
                          "process; a data-parallel reducer keeps the whole update in step()).  Bit-identical values.")
-    ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict"],
+    ap.add_argument("--fit-source", default="synthetic", choices=["synthetic", "jpeg", "png"],
+                    help="--workload fit: `synthetic: true` dataset, or an on-disk image list written to --fit-dir and "
+                         "decoded by ImageDataset (PIL)")
+    ap.add_argument("--fit-workers", type=int, default=8, help="--workload fit: DataLoader workers (the YAML's num_workers)")
+    ap.add_argument("--fit-files", type=int, default=2048, help="--workload fit: images written to disk (epochs cycle)")
+    ap.add_argument("--fit-dir", default="/tmp/d3f_fit_data")
+    ap.add_argument("--fit-uint8", default="off", choices=["on", "off"],
+                    help="--workload fit with an on-disk list: `uint8_batches: true` -- workers hand over HWC uint8 images, "
+                         "Normalize + ToTensor run on the GPU (bit-identical)")
+    ap.add_argument("--fit-pin", default="on", choices=["on", "off"], help="--workload fit: DataLoader(pin_memory=...)")
+    ap.add_argument("--fit-augment", default="on", choices=["on", "off"],
+                    help="--workload fit: the random affine warp of training_step (the reference always augments)")
+    ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict", "fit"],
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
@@ -161,8 +173,138 @@ def alt_dtype(args, dev, dtype):
             "graph_step": not lit.automatic_optimization, "note": ALT_NOTES[dtype]}
 
 
+def write_image_list(args):
+    """`--fit-files` synthetic face crops as uint8 RGB files + images.txt (the reference's dataset format,
+    d3f/dataset/image_dataset.py:19-31: paths relative to the list's own directory)"""
+    from PIL import Image
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    ext = "jpg" if args.fit_source == "jpeg" else "png"
+    root = os.path.join(args.fit_dir, f"{args.fit_source}_{args.size}_{args.fit_files}")
+    lst = os.path.join(root, "images.txt")
+    if os.path.exists(lst):
+        return lst
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    names = []
+    for i0 in range(0, args.fit_files, 64):
+        x = synthetic_face_crops(min(64, args.fit_files - i0), args.size, seed=5000 + i0)
+        u8 = ((x * 0.5 + 0.5) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+        for j in range(u8.shape[0]):
+            name = f"images/{i0 + j:06d}.{ext}"
+            Image.fromarray(u8[j]).save(os.path.join(root, name), **({"quality": 92} if ext == "jpg" else {}))
+            names.append(name)
+    with open(lst + ".tmp", "w") as f:
+        f.write("\n".join(names) + "\n")
+    os.replace(lst + ".tmp", lst)
+    return lst
+
+
+def fit_workload(args):
+    """END TO END: images/s through Trainer.fit -> DataLoader (spawned workers) -> _to_device -> (affine warp) -> noise
+    blend -> U-Net step, next to the same step on resident batches (what `python bench.py` times) and to the loader and
+    the host->device copy on their own.  Replaces the reference's fit loop around d3f/train_denoiser/lit_module.py:72-126
+    (dataloader :72-90, training_step :107-126) and d3f/dataset/image_dataset.py:33-44."""
+    import tempfile
+    from denoising_diffusion_deep_fake_amd.trainer import Callback, Trainer, _to_device
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    total = args.warmup + args.steps
+    hp = dict(batch_size=args.batch, learning_rate=0.02, max_epochs=10 ** 6, cosine_scheduler_max_epoch=10 ** 6,
+              num_workers=args.fit_workers, encoder_name="resnet34", noise_exponential_sampling_lambda=5,
+              mean=[128, 128, 128], std=[128, 128, 128], image_size=args.size, augment=args.fit_augment == "on",
+              precision=args.dtype, uint8_batches=args.fit_uint8 == "on", pin_memory=args.fit_pin == "on")
+    if args.fit_source == "synthetic":
+        hp.update(synthetic=True, synthetic_length=args.fit_files)
+    else:
+        t0 = time.perf_counter()
+        hp.update(synthetic=False, input_image_list_path=write_image_list(args))
+        log(f"image list ready in {time.perf_counter() - t0:.1f}s: {hp['input_image_list_path']}")
+    lit = LitModule(**hp)
+
+    # (1) the loader alone: batches/s the workers can deliver to the main process (no GPU work)
+    loader = lit.train_dataloader()
+    it = iter(loader)
+    first = next(it)
+    nb, t0 = 0, time.perf_counter()
+    for batch in it:
+        nb += 1
+        if nb >= 40:
+            break
+    loader_s = (time.perf_counter() - t0) / max(nb, 1)
+    img = first["image"]
+    batch_bytes = img.numel() * img.element_size()
+    # (2) host -> device copy of one batch as the trainer does it
+    _to_device(first, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        _to_device(first, dev)
+    torch.cuda.synchronize()
+    h2d_s = (time.perf_counter() - t0) / 10
+    del it, loader
+    log(f"loader alone: {1e3 * loader_s:.2f} ms/batch ({args.batch / loader_s:.0f} images/s), H2D {1e3 * h2d_s:.2f} ms/batch")
+
+    # (3) Trainer.fit
+    class Clock(Callback):
+        def __init__(self):
+            self.t0 = self.t1 = None
+            self.n = 0
+
+        def on_train_batch_end(self, trainer, module):
+            self.n += 1
+            if self.n == args.warmup:
+                torch.cuda.synchronize()
+                self.t0 = time.perf_counter()
+            elif self.n == total:
+                torch.cuda.synchronize()
+                self.t1 = time.perf_counter()
+    clock = Clock()
+    with tempfile.TemporaryDirectory() as tmp:
+        tr = Trainer(max_epochs=10 ** 6, max_steps=total, callbacks=[clock], enable_checkpointing=False,
+                     default_root_dir=tmp, log_every_n_steps=50)
+        tr.fit(lit)
+    fit_s = (clock.t1 - clock.t0) / args.steps
+    lossv = float(lit._logged["loss"])
+
+    # (4) the same step on resident batches in the same process (what the headline bench times)
+    (opt,) = tr.optimizers
+    data = [first["image"].to(dev) if first["image"].dtype == torch.float32 else None for _ in range(1)]
+    if data[0] is None:
+        data = [lit.normalise_on_device(first["image"].to(dev))]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = lit.training_step({"image": data[0], "index": None}, 0)
+        loss.backward()
+        opt.step()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(min(args.steps, 50)):
+        step()
+    torch.cuda.synchronize()
+    res_s = (time.perf_counter() - t0) / min(args.steps, 50)
+    out = {"workload": f"Trainer.fit end to end: d3f train_denoiser, {args.size}x{args.size}, bs={args.batch}, "
+                       f"{args.fit_source} dataset, {args.fit_workers} DataLoader workers, augment {args.fit_augment}, "
+                       f"uint8 batches {args.fit_uint8}, pinned {args.fit_pin}",
+           "dtype": args.dtype, "steps": args.steps, "warmup": args.warmup,
+           "images_per_sec_fit": round(args.batch / fit_s, 1), "ms_per_step_fit": round(1e3 * fit_s, 3),
+           "images_per_sec_resident_same_process": round(args.batch / res_s, 1), "ms_per_step_resident": round(1e3 * res_s, 3),
+           "fit_over_resident": round(res_s / fit_s, 4),
+           "loader_alone_images_per_sec": round(args.batch / loader_s, 1), "loader_alone_ms_per_batch": round(1e3 * loader_s, 3),
+           "loader_share_of_fit_step": round(min(1.0, loader_s / fit_s), 3),
+           "batch_dtype_from_loader": str(img.dtype).replace("torch.", ""), "batch_bytes": batch_bytes,
+           "h2d_ms_per_batch": round(1e3 * h2d_s, 3), "h2d_GBps": round(batch_bytes / h2d_s / 1e9, 2),
+           "host_cores": usable_cores(), "final_loss": round(lossv, 5)}
+    print(json.dumps(out), flush=True)
+
+
 def extra_workload(args):
     """secondary workloads of BASELINE.json (not the headline metric): one JSON line each."""
+    if args.workload == "fit":
+        return fit_workload(args)
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "d3f_l1_per_image_workspace_bytes": (_sz, [_i]),
     "d3f_l1_per_image": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
     "d3f_affine_warp": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "d3f_u8rgb_normalise": (_i, [_p, _p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _p]),
     "d3f_unet_predict_u8": (_i, [_p, _p, _p, _p, _p, C.POINTER(_f), C.POINTER(_f), _p, _i, _p]),
     "d3f_unet_num_segments": (_i, [_p]),
     "d3f_unet_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),

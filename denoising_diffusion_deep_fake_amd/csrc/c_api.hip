@@ -566,6 +566,15 @@ int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int
   D3F_CHECK(dfull && dlow, "upsample2x_backward: null argument");
   return sum2x2_launch(sdt(dtype), dfull, dlow, B, Hlow, Wlow, C, (hipStream_t)stream);
 }
+int d3f_u8rgb_normalise(const uint8_t* in_hwc, float* out_nchw, int B, int H, int W, const float mean[3],
+                        const float std[3], void* stream) {
+  if (B == 0) return 0;
+  D3F_CHECK(in_hwc && out_nchw && mean && std, "u8rgb_normalise: null argument");
+  D3F_CHECK(B > 0 && H > 0 && W > 0, "u8rgb_normalise: bad shape");
+  D3F_CHECK(std[0] != 0.f && std[1] != 0.f && std[2] != 0.f, "u8rgb_normalise: zero std");
+  return u8rgb_to_nchw_launch(in_hwc, out_nchw, B, (long)H * W, mean, std, (hipStream_t)stream);
+}
+
 int d3f_affine_warp(const float* in, const float* theta, float* out, int B, int C, int H, int W, void* stream) {
   if (B == 0) return 0;
   D3F_CHECK(in && theta && out && in != out, "affine_warp: null or aliased argument");

@@ -82,6 +82,10 @@ int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int
 int nchw_to_u8bgr_launch(const float* in, uint8_t* out, int B, long HW, const float mean255[3],
                          const float std255[3], hipStream_t stream);
 
+// input pipeline: uint8 RGB [B][H][W][3] -> NCHW fp32, ((float)u8 / 255 - mean[c]) / std[c]
+int u8rgb_to_nchw_launch(const uint8_t* in, float* out, int B, long HW, const float mean[3], const float stdv[3],
+                         hipStream_t stream);
+
 // K17: affine_grid + grid_sample(bilinear, zeros, align_corners=False) on NCHW fp32, theta [B][2][3]
 int affine_warp_launch(const float* in, const float* theta, float* out, int B, int C, int H, int W,
                        hipStream_t stream);

@@ -690,6 +690,24 @@ __global__ __launch_bounds__(256) void nchw_to_u8bgr_kernel(const float* __restr
   }
 }
 
+// Input pipeline: uint8 RGB frames [B][H][W][3] as PIL decodes them -> normalised NCHW fp32 training batch,
+// ((float)u8 / 255 - mean) / std in the order of fp32 operations of albumentations.Normalize(max_pixel_value=255) +
+// ToTensorV2 (d3f/train_deep_fake/lit_module.py:100-110) -- bit-identical to the host transform, but the batch crosses
+// worker IPC and PCIe as 1 byte per value instead of 4.
+__global__ __launch_bounds__(256) void u8rgb_to_nchw_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                            int B, long HW, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, pix = i - b * HW;
+    const uint8_t* px = in + i * 3;
+    float* o = out + b * 3 * HW + pix;
+    o[0] = ((float)px[0] / 255.0f - m0) / s0;
+    o[HW] = ((float)px[1] / 255.0f - m1) / s1;
+    o[2 * HW] = ((float)px[2] / 255.0f - m2) / s2;
+  }
+}
+
 // K17: batched affine warp of NCHW fp32 images -- affine_grid + grid_sample(bilinear, zeros, align_corners=False)
 // in one pass (the GPU-side augmentation of train_denoiser, d3f/train_denoiser/lit_module.py:55-65,113).
 // theta [B][2][3] maps normalised output coordinates to normalised input coordinates.
@@ -741,6 +759,15 @@ int u8bgr_to_nhwc_launch(int dtype, const uint8_t* in, void* out, long npix, int
   else
     hipLaunchKernelGGL(u8bgr_to_nhwc_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, stream, in, (bf16_t*)out,
                        npix, Cpad, mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2]);
+  D3F_HIP(hipGetLastError());
+  return 0;
+}
+
+int u8rgb_to_nchw_launch(const uint8_t* in, float* out, int B, long HW, const float mean[3], const float stdv[3],
+                         hipStream_t stream) {
+  if ((long)B * HW == 0) return 0;
+  hipLaunchKernelGGL(u8rgb_to_nchw_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, stream, in, out, B, HW, mean[0],
+                     mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
   D3F_HIP(hipGetLastError());
   return 0;
 }

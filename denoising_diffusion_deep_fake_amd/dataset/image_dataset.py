@@ -62,6 +62,16 @@ class SyntheticFaceDataset(Dataset):
         return {"image": synthetic_face_crops(1, self.size, self.seed + index)[0], "index": index}
 
 
+class ToUint8Tensor:
+    """albumentations-style callable `t(image=HWC uint8)["image"] -> HWC uint8 tensor` (no arithmetic on the host): the
+    Normalize + ToTensorV2 half of the reference's A.Compose then runs on the GPU inside training_step
+    (ops.u8rgb_normalise, bit-identical to NormalizeToTensor) and the batch crosses worker IPC and PCIe as one byte per
+    value instead of four.  Opt-in through the hyper-parameter `uint8_batches: true`."""
+
+    def __call__(self, image):
+        return {"image": torch.from_numpy(np.ascontiguousarray(image))}
+
+
 class NormalizeToTensor:
     """albumentations-style callable `t(image=HWC uint8)["image"] -> CHW float`:
     Normalize(mean, std, max_pixel_value=255) + ToTensorV2 (train_deep_fake/lit_module.py:100-110,

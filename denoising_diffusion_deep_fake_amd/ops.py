@@ -210,6 +210,20 @@ def affine_warp(x, theta):
     return out
 
 
+def u8rgb_normalise(frames, mean, std):
+    """uint8 RGB [B, H, W, 3] on the HIP device -> normalised NCHW float32 ((u8 / 255 - mean) / std per channel): the
+    host transform NormalizeToTensor bit for bit (d3f_u8rgb_normalise)"""
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise ValueError("u8rgb_normalise expects uint8 frames [B, H, W, 3] (RGB)")
+    frames = frames.contiguous()
+    B, H, W, _ = frames.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=_dev(frames))
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().d3f_u8rgb_normalise(ptr(frames), ptr(out), B, H, W, m, s, stream_ptr()))
+    return out
+
+
 def noise_blend(x, noise, y_uniform, lam, return_r=False):
     x = x.contiguous().float()
     out = torch.empty_like(x)

@@ -19,7 +19,7 @@ import torch.optim.lr_scheduler as schedulers
 from torch.utils.data import DataLoader
 
 from .. import ops
-from ..dataset.image_dataset import ImageDataset, NormalizeToTensor, SyntheticFaceDataset
+from ..dataset.image_dataset import ImageDataset, NormalizeToTensor, SyntheticFaceDataset, ToUint8Tensor
 from ..lightning import LightningModule
 from ..loss_functions import MseStructuralSimilarityLoss
 from ..optim import FusedAdam
@@ -85,14 +85,31 @@ class LitModule(LightningModule):
             dataset = SyntheticFaceDataset(p.get("synthetic_length", 64 * p.batch_size), p.get("image_size", 256))
         else:
             # config means/stds are in 0..255 units (denoiser_config.yml:10-11) -> [0,1] units here
-            m = [v / 255.0 if max(mean) > 1 else v for v in mean]
-            s = [v / 255.0 if max(std) > 1 else v for v in std]
-            dataset = ImageDataset(path, transform=NormalizeToTensor(m, s))
+            m, s = self.mean_std_unit()
+            # uint8_batches: true -- the workers hand over the decoded HWC uint8 image, Normalize + ToTensor run on the
+            # device in training_step (normalise_on_device; bit-identical, 4x fewer bytes through IPC and PCIe)
+            dataset = ImageDataset(path, transform=ToUint8Tensor() if p.get("uint8_batches", False) else NormalizeToTensor(m, s))
         workers = p.get("num_workers", 0)
         # shuffle=True, ragged last batch kept (d3f/train_denoiser/lit_module.py:78-86); workers are SPAWNED: forking
         # a process that has initialised HIP is not safe
-        extra = dict(multiprocessing_context="spawn", persistent_workers=True) if workers > 0 else {}
-        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=workers, shuffle=True, **extra)
+        extra = dict(multiprocessing_context="spawn", persistent_workers=True,
+                     prefetch_factor=p.get("prefetch_factor", 2)) if workers > 0 else {}
+        # pin_memory: the trainer's `.to(device, non_blocking=True)` is only asynchronous from page-locked memory
+        return DataLoader(dataset=dataset, batch_size=p.batch_size, num_workers=workers, shuffle=True,
+                          pin_memory=bool(p.get("pin_memory", True)) and torch.cuda.is_available(), **extra)
+
+    def mean_std_unit(self):
+        """config means / stds are in 0..255 units (denoiser_config.yml:10-11) -> [0, 1] units"""
+        p = self.hparams
+        mean, std = p.get("mean"), p.get("std")
+        return ([v / 255.0 if max(mean) > 1 else v for v in mean], [v / 255.0 if max(std) > 1 else v for v in std])
+
+    @torch.no_grad()
+    def normalise_on_device(self, frames_u8):
+        """[B, H, W, 3] uint8 RGB batch of a `uint8_batches: true` loader -> the normalised NCHW float batch the host
+        transform would have produced (bit-identical)"""
+        m, s = self.mean_std_unit()
+        return ops.u8rgb_normalise(frames_u8, m, s)
 
     def configure_optimizers(self):
         p = self.hparams
@@ -108,6 +125,8 @@ class LitModule(LightningModule):
 
     def training_step(self, batch, batch_idx):
         image = batch["image"]
+        if image.dtype == torch.uint8:
+            image = self.normalise_on_device(image)
         if self.hparams.get("augment", True):
             with torch.no_grad():
                 image = self.shared_augmentation_sequence(image)

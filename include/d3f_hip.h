@@ -236,6 +236,13 @@ int d3f_maxpool3x3s2_backward(int dtype, const void* dout, const uint8_t* idx, v
 int d3f_upsample2x_backward(int dtype, const void* dfull, void* dlow, int B, int Hlow, int Wlow, int C, void* stream);
 int d3f_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad, void* stream);
 int d3f_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad, void* stream);
+/* Host half of the input pipeline moved to the device (d3f/train_deep_fake/lit_module.py:100-110: A.Normalize(mean, std,
+ * max_pixel_value=255) + ToTensorV2 on the HWC uint8 RGB image d3f/dataset/image_dataset.py:37-41 hands the transform):
+ * in_hwc [B][H][W][3] uint8 RGB -> out_nchw [B][3][H][W] f32 = ((float)u8 / 255 - mean[c]) / std[c], the transform's
+ * own order of fp32 operations (bit-identical); the batch crosses worker IPC and PCIe as bytes. */
+int d3f_u8rgb_normalise(const uint8_t* in_hwc, float* out_nchw, int B, int H, int W, const float mean[3],
+                        const float std[3], void* stream);
+
 /* GPU-side augmentation of the training step (d3f/train_denoiser/lit_module.py:55-65 RandomAffine, applied at :113):
  * out[b] = grid_sample(in[b], affine_grid(theta[b]), bilinear, zeros padding, align_corners=False), NCHW f32,
  * theta [B][2][3] row-major (normalised output -> input coordinates).  in and out must not alias. */

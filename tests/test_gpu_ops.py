@@ -457,3 +457,26 @@ def test_empty_batches_are_no_ops(ops):
     dw = ops.conv_backward_weight(d, torch.zeros(0, 16, 16, 32, device="cuda"), torch.zeros(0, 16, 16, 32, device="cuda"), None)
     torch.cuda.synchronize()
     assert dw.shape == w.shape and float(dw.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 48), (1, 7, 5)], ids=str)
+def test_u8rgb_normalise_is_the_host_transform_bit_for_bit(shape):
+    """d3f_u8rgb_normalise (the `uint8_batches: true` input pipeline): HWC uint8 RGB -> normalised NCHW fp32 must equal
+    the host transform NormalizeToTensor = A.Normalize(mean, std, max_pixel_value=255) + ToTensorV2
+    (/root/reference/d3f/train_deep_fake/lit_module.py:100-110) BIT FOR BIT, every byte value in every channel."""
+    import numpy as np
+    from denoising_diffusion_deep_fake_amd import ops
+    from denoising_diffusion_deep_fake_amd.dataset.image_dataset import NormalizeToTensor
+    B, H, W = shape
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    img.reshape(-1, 3)[:256] = np.arange(256, dtype=np.uint8)[:, None][:min(256, B * H * W)]   # every byte value, every channel
+    for mean, std in (([0.5, 0.5, 0.5], [0.5, 0.5, 0.5]), ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]),
+                      ([128 / 255.0] * 3, [128 / 255.0] * 3)):
+        t = NormalizeToTensor(mean, std)
+        want = torch.stack([t(image=img[b])["image"] for b in range(B)])
+        got = ops.u8rgb_normalise(torch.from_numpy(img).cuda(), mean, std)
+        assert got.shape == (B, 3, H, W) and got.dtype == torch.float32
+        assert torch.equal(got.cpu(), want), (mean, std, (got.cpu() - want).abs().max())
+    with pytest.raises(ValueError):
+        ops.u8rgb_normalise(torch.zeros(2, 3, 8, 8, dtype=torch.uint8, device="cuda"), [0.5] * 3, [0.5] * 3)
