@@ -375,6 +375,8 @@ def extra_workload(args):
         def step(i):
             return optimizer_steps(lit, opts, opt_params, batch, i, True, streams)
         images_per_step = 2 * bs
+        fwd_fl, bwd_fl = lit.model_a.conv_flops(bs, args.size, args.size, dev)
+        flops_per_step = 2 * (fwd_fl + bwd_fl)  # two nets, one training step each per combined batch
         name = (f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain, the two optimizer steps "
                 f"{'overlapped on two streams' if streams else 'one after the other'}")
     else:
@@ -412,6 +414,7 @@ def extra_workload(args):
         bitwise = bool(torch.equal(ref, xbuf))
         images_per_step, name = 64, ("50 eval-mode forwards (BatchNorm folded) of a batch of 64, output fed back; "
                                      "denoise step replayed from a hipGraph")
+        flops_per_step = 50 * net.conv_flops(64, args.size, args.size, dev)[0]
         extra = {"ms_per_step_eager": round(eager_ms, 3), "replay_equals_eager_bitwise": bitwise}
     for i in range(args.warmup):
         out = step(i)
@@ -424,6 +427,14 @@ def extra_workload(args):
     res = {"workload": name, "dtype": args.dtype, "image_size": args.size, "steps": args.steps,
            "ms_per_step": round(1e3 * dt / args.steps, 3),
            "images_per_sec": round(images_per_step * args.steps / dt, 2), "last": float(out.item())}
+    # whole-workload roofline: algorithmic conv FLOPs (2 x MACs of the ORIGINAL convolutions, SURVEY.md 8d -- Winograd /
+    # folded / class-form kernels are credited the direct count) over the wall time of the timed steps, against the
+    # dense MFMA peak of the arithmetic type; everything that is not a contraction (BatchNorm, loss, Adam) is inside `dt`
+    tf = flops_per_step * args.steps / dt / 1e12
+    res["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                       "frac": round(tf / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                       "basis": "whole timed region (all kernels), conv FLOPs counted as the direct convolution's",
+                       "conv_gflop_per_step": round(flops_per_step / 1e9, 2)}
     if args.workload == "sample50":
         res.update(extra)
     print(json.dumps(res), flush=True)

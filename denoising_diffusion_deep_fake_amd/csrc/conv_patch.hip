@@ -36,9 +36,13 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   // C0 == 4: the data gradient of the segmentation head (dY has 3 channels padded to 4, 16 outputs): as an implicit
   // GEMM it ran 110 us in the traced step for 17 MB in / 67 MB out (profiles/r03_z_step_launches.txt)
   // bf16 storage (round 3): the 16-channel form on v_mfma_f32_16x16x16_bf16, one instruction per tap and fragment
-  const bool cin_ok = p.C0 == 16 || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
+  // bf16, 32 channels -> <= 32 filters (round 5: decoder block 3 conv2 forward + data gradient at 128x128): a pixel is
+  // 64 bytes like fp32 x 16 channels, so the staged image is the fp32 one byte for byte; one v_mfma_f32_16x16x32_bf16
+  // contracts a whole tap
+  const bool wide = p.C0 == 32 && dtype == D3F_BF16 && p.mode != CONV_HEAD_NCHW;
+  const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
-         p.shift0 == 0 && p.zi == 0 && p.Cout <= 16 && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
+         p.shift0 == 0 && p.zi == 0 && p.Cout <= (wide ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
          (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
@@ -47,23 +51,26 @@ template <typename T, int CIN, int BN>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
   constexpr bool BF = sizeof(T) == 2;
-  static_assert((CIN == 16 || (CIN == 4 && !BF)) && BN == 16, "16 channels (forward / data gradient of decoder block 4, "
-                                                               "head forward) or, fp32, 4 (data gradient of the head)");
+  // W64: bf16 x 32 channels -- 64-byte pixels, 32 filters (decoder block 3 conv2)
+  constexpr bool W64 = BF && CIN == 32;
+  static_assert(((CIN == 16 || (CIN == 4 && !BF)) && BN == 16) || (W64 && BN == 32),
+                "16 channels (forward / data gradient of decoder block 4, head forward), fp32 x 4 (data gradient of the "
+                "head) or bf16 x 32 -> 32 (decoder block 3 conv2)");
   constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte vector
   constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
   // dwords per staged pixel: such that the fragment reads spread over the banks (fp32 CIN 16: +4 pad, 16-byte reads;
   // CIN 4: stride 12, scalar reads; bf16: 32 B of channels + 8 B pad = 10 dwords -- 10 * row covers the even banks
   // over 16 rows, the 8-byte fragment reads are conflict-free; the staging stores are 8-byte halves)
-  constexpr int CS = BF ? 10 : (CIN == 16 ? CIN + 4 : 12);
+  constexpr int CS = W64 ? 20 : BF ? 10 : (CIN == 16 ? CIN + 4 : 12);
   constexpr int KR = 9 * CIN;        // real k extent
   // dwords per staged weight row (fp32 CIN 16: no pad, 16-byte chunks XOR-swizzled by the row; CIN 4: +4 pad, no
   // swizzle; bf16: 72 dwords of taps + 2 = 74: the same stride-10-mod-32 pattern over the filter rows)
-  constexpr int WS = BF ? KR / 2 + 2 : (CIN == 16 ? KR : KR + 4);
+  constexpr int WS = W64 ? KR / 2 : BF ? KR / 2 + 2 : (CIN == 16 ? KR : KR + 4);
   constexpr int CV = CIN / VEC;        // 16-byte vectors per pixel
   constexpr int NPV = PR * PC * CV;    // patch vectors
   constexpr int NWV = BN * (KR / VEC); // weight vectors
   constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
-  constexpr int BM = PH * PW, LDC = BN + 4, FM = PW / 16;
+  constexpr int BM = PH * PW, LDC = BN + 4, FM = PW / 16, NB = BN / 16;
   constexpr int PATCH_DW = PR * PC * CS > BM * LDC ? PR * PC * CS : BM * LDC;  // the C tile aliases the patch
   __shared__ __attribute__((aligned(16))) float lds[PATCH_DW + BN * WS];
   float* P = lds;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
     const int id = tid + 256 * i;
     const int pix = id / CV, cv = id - pix * CV;
     if (NPV % 256 == 0 || id < NPV) {
-      if constexpr (BF) {  // 40-byte pixels: two 8-byte stores
+      if constexpr (BF && !W64) {  // 40-byte pixels: two 8-byte stores
         *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4]) = make_uint2(pv[i].x, pv[i].y);
         *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4 + 2]) = make_uint2(pv[i].z, pv[i].w);
       } else {
@@ -113,11 +120,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
     const int id = tid + 256 * i;
     const int row = id / (KR / VEC), ch = id - row * (KR / VEC);
     if (NWV % 256 == 0 || id < NWV) {
-      if constexpr (BF) {
+      if constexpr (BF && !W64) {
         *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4]) = make_uint2(wv[i].x, wv[i].y);
         *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4 + 2]) = make_uint2(wv[i].z, wv[i].w);
       } else {
-        const int chs = CIN == 16 ? (ch ^ ((row >> 1) & 3)) : ch;
+        const int chs = (CIN == 16 || W64) ? (ch ^ ((row >> 1) & 3)) : ch;
         *reinterpret_cast<uint4*>(&Wl[row * WS + chs * 4]) = wv[i];
       }
     }
@@ -129,10 +136,29 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   // 16-byte read gives a lane channels 4*fq .. 4*fq+3 of its pixel / filter: MFMA e of a tap contracts the channel
   // set {e, 4+e, 8+e, 12+e} -- the same permutation on both operands.
   const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[FM];
+  f32x4 acc[FM * NB];  // [fragment i][16-filter group j] at i * NB + j
 #pragma unroll
-  for (int i = 0; i < FM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (BF) {
+  for (int i = 0; i < FM * NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (W64) {
+    // lane holds channels 8 fq .. 8 fq + 7 (16 bytes) of its pixel / filter: one MFMA contracts the tap's 32 channels
+    const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
+    const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // (rows fr and fr + 16 share the swizzle)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      uint4 bb[NB], a[FM];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bb[j] = *reinterpret_cast<const uint4*>(Bbase + j * 16 * WS + tap * (CIN / 2));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(Abase + ((kh * PC + kw) + i * 16) * CS);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[i]),
+                                                                    *reinterpret_cast<const bf16x8*>(&bb[j]), acc[i * NB + j], 0, 0, 0);
+    }
+  } else if constexpr (BF) {
     // bf16: v_mfma_f32_16x16x16_bf16 contracts all 16 channels of a tap at once: lane holds channels 4 fq .. 4 fq + 3
     // (8 bytes) of its pixel / filter
     typedef short v4s __attribute__((ext_vector_type(4)));
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   // accumulator register r of fragment i = out[pixel (y0 + wave, x0 + 16 i + 4 fq + r)][n = fr]
   const int HoWo = p.Ho * p.Wo;
   const long mrow0 = ((long)b * p.Ho + y0) * p.Wo + x0;  // output row (pixel index) of the tile's first pixel
-  if (p.mode == CONV_HEAD_NCHW) {  // + bias, fp32 NCHW: a lane's four registers are four consecutive pixels
+  if (NB == 1 && p.mode == CONV_HEAD_NCHW) {  // + bias, fp32 NCHW: a lane's four registers are four consecutive pixels
     if (fr < p.Cout) {
       float* __restrict__ out = reinterpret_cast<float*>(p.out0);
       const float bias = p.scale ? p.scale[fr] : 0.f;
@@ -207,7 +233,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Cs[(wave * PW + i * 16 + 4 * fq + r) * LDC + fr] = acc[i][r];
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(wave * PW + i * 16 + 4 * fq + r) * LDC + j * 16 + fr] = acc[i * NB + j][r];
   __syncthreads();
 
   constexpr int VN = BN / 4, NVEC = BM * VN / 256, RSTEP = 256 / VN;
@@ -515,7 +543,7 @@ void conv_patch_plan(ConvParams& p, int dtype) {
     p.stat_rows = p.tiles_m;
     return;
   }
-  p.patch = dtype == D3F_BF16 ? 3 : 1;  // 3: the bf16-storage instantiation
+  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? 4 : 3) : 1;  // 3 / 4: the bf16-storage instantiations (16 / 32 channels)
   p.nz = 1;
   p.splitk = 1;
   p.w_ld = p.Kpad;
@@ -532,10 +560,11 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK((p.patch == 1 || p.patch == 3) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
-                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1)) && p.Cout <= 16,
+  D3F_CHECK((p.patch == 1 || p.patch == 3 || p.patch == 4) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
+                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && p.patch == 4)) && p.Cout <= (p.patch == 4 ? 32 : 16),
             "conv: patch params were not planned");
-  if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   D3F_HIP(hipGetLastError());

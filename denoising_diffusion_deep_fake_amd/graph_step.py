@@ -98,6 +98,7 @@ class GraphTrainStep:
         if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
             raise NotImplementedError("FusedAdam implements plain Adam")
         opt._step += 1
+        opt._opt_called = True  # the fused step IS this optimiser's step: torch's lr_scheduler.step() order check reads the flag
         L = _lib.lib()
         k = self._slot % self.RING
         self._slot += 1
