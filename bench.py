@@ -65,7 +65,7 @@ def parse():
                          "~30 us per node; captured on one stream it equals the eager single-stream step) -- off by default")
     ap.add_argument("--dp-buckets", type=int, default=4, choices=[1, 2, 4],
                     help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 4 = one per "
-                         "engine segment (default), 2 = (head .. layer4) | (layer3 .. stem), 1 = one all-reduce at the end")
+                         "engine segment (default), 2 = (head .. layer3) | (layer2 .. stem), 1 = one all-reduce at the end")
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "180")),
                     help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
                          "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")
@@ -493,7 +493,7 @@ def dp_selftest(args):
         torch.cuda.synchronize()
         return lit.model.flat_grads.clone()
 
-    variants = (None, 4, 2, 1)
+    variants = (None, 4, 2, ((0, 2), (2, 4)), 1)  # 2 = (head .. layer3) | (layer2 .. stem); explicit: the halves by segment count
     for i in range(args.warmup):
         mode(variants[i % len(variants)])
         step(i)
@@ -511,6 +511,8 @@ def dp_selftest(args):
             torch.cuda.synchronize()
             times[b].append(1e3 * (time.perf_counter() - t0) / args.steps)
             log(f"dp-selftest round {r} {str(b) + ' buckets + RCCL' if b else 'plain'}: {times[b][-1]:.3f} ms/step")
+    def label(b):
+        return "plain" if b is None else f"buckets{b}" if isinstance(b, int) else "buckets2_by_segments"
     plain, buck = min(times[None]), min(times[4])
     segs = lit.model._rt["last_engine"].seg_ranges
     res = {"workload": f"dp-selftest: d3f train_denoiser step at N=1, plain vs 4 / 2 / 1 gradient buckets all-reduced over a "
@@ -518,8 +520,8 @@ def dp_selftest(args):
            "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "steps": args.steps, "rounds": rounds,
            "ms_per_step_plain": round(plain, 3), "ms_per_step_bucketed_rccl": round(buck, 3),
            "dp_tax": round(buck / plain - 1.0, 4),
-           "dp_tax_by_buckets": {str(b): round(min(times[b]) / plain - 1.0, 4) for b in variants[1:]},
-           "all_rounds_ms": {("plain" if b is None else f"buckets{b}"): [round(t, 3) for t in times[b]] for b in variants},
+           "dp_tax_by_buckets": {label(b): round(min(times[b]) / plain - 1.0, 4) for b in variants[1:]},
+           "all_rounds_ms": {label(b): [round(t, 3) for t in times[b]] for b in variants},
            "bucket_mb": [round(4e-6 * (e - b), 1) for b, e in segs],
            "gradients_bit_identical_to_plain": identical, "final_loss": round(float(loss.item()), 5),
            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")}}

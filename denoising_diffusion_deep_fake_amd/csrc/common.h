@@ -247,8 +247,7 @@ struct WgradParams {
   int M;        // B*Ho*Wo
   int cin_real; // real (unpadded) input channels when the caller knows them, else 0 = every channel counts
   int splits;   // pixel slabs
-  int ps;       // pixel ranges per workgroup, summed inside the workgroup into ONE slab (tap-parallel 64x64 kernel; else 1)
-  int chunks_per_split;  // 32-pixel chunks per pixel range (a slab covers ps ranges)
+  int chunks_per_split;  // 32-pixel chunks per slab
   int tiles_co, tiles_ci;
   int patch;     // 0: tap-parallel kernel; >0: variant of the persistent patch kernel (conv_wgrad_patch.hip)
   double flops;  // algorithmic FLOPs of this launch, for profiling

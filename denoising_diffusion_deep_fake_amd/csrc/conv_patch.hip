@@ -39,7 +39,11 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   // bf16, 32 channels -> <= 32 filters (round 5: decoder block 3 conv2 forward + data gradient at 128x128): a pixel is
   // 64 bytes like fp32 x 16 channels, so the staged image is the fp32 one byte for byte; one v_mfma_f32_16x16x32_bf16
   // contracts a whole tap
+#ifdef D3F_NO_PATCH32  // A/B builds only (make EXTRA=-DD3F_NO_PATCH32): the implicit GEMM for these layers, as before round 5
+  const bool wide = false;
+#else
   const bool wide = p.C0 == 32 && dtype == D3F_BF16 && p.mode != CONV_HEAD_NCHW;
+#endif
   const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
          p.shift0 == 0 && p.zi == 0 && p.Cout <= (wide ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&

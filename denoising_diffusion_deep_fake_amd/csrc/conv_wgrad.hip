@@ -70,15 +70,9 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // neighbourhood); the k-loop runs over the LOW-resolution pixel grid (b, j, i): dY is read at (2j + py, 2i + px), the
 // source at (j + a - 1 + py, i + b - 1 + px) -- the low-resolution pixel under up-sampled row 2j + py + kh - 1 for the
 // taps kh that share `a` (kh = 0 | 1,2 for py = 0; kh = 0,1 | 2 for py = 1; columns alike).
-//
-// PS (WgradParams::ps): in-CU reduction over pixel ranges.  A workgroup is PS groups of 256 threads; group g runs the
-// loop above over pixel range `slab * PS + g` of the same (tap, co tile, ci tile) in its own LDS region, and the groups'
-// accumulators are summed through LDS in group order (a fixed tree: bitwise reproducible) before ONE slab is stored --
-// 1/PS of the slab bytes written here and re-read by the reduce, at the same waves and LDS bytes per CU.
-template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false, int PS = 1>
-__global__ __launch_bounds__(256 * PS) void conv_wgrad_kernel(const WgradParams p) {
+template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
-  static_assert(PS == 1 || (KSPLIT == 1 && BMW == 64 && BNW == 64), "pixel-range groups: 64x64 tile only");
 
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
   // bf16 storage: the same k-major staging with ONE plane (the operands are bf16 already) = native bf16 MFMA
@@ -93,14 +87,11 @@ __global__ __launch_bounds__(256 * PS) void conv_wgrad_kernel(const WgradParams 
   constexpr int X3_SUB = KP * 64, X3_PLANE = 2 * X3_SUB, X3_OP = (sizeof(T) == 4 ? 3 : 1) * X3_PLANE;  // bytes
   constexpr int F32_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
   constexpr int LDS_FLOATS = X3 ? 2 * X3_OP / 4 : F32_FLOATS;
-  static_assert(PS == 1 || (PS - 1) * BMW * BNW <= PS * LDS_FLOATS, "the groups' accumulators are exchanged through the staging LDS");
-  __shared__ __attribute__((aligned(16))) float lds_all[PS * LDS_FLOATS];
-  const int grp = PS > 1 ? (int)(threadIdx.x >> 8) : 0;  // pixel-range group of this thread (wave-uniform)
-  float* lds = lds_all + grp * LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* Ys = lds;
   float* Xs = lds + KP * LY;
 
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % KSPLIT;
   const int wmn = wave / KSPLIT;
   const int wm = wmn / WGN, wn = wmn % WGN;
@@ -165,14 +156,10 @@ __global__ __launch_bounds__(256 * PS) void conv_wgrad_kernel(const WgradParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int chunk_begin = (split * PS + grp) * p.chunks_per_split;
+  const int chunk_begin = split * p.chunks_per_split;
   int chunk_end = chunk_begin + p.chunks_per_split;
-  if constexpr (PS == 1) {
-    const int total_chunks = (p.Mi + KP - 1) / KP;
-    if (chunk_end > total_chunks) chunk_end = total_chunks;
-  }
-  // PS > 1: every group runs chunks_per_split iterations (the barriers are the workgroup's); chunks past the end of the
-  // pixel grid load zeros through the row test of load_chunk
+  const int total_chunks = (p.Mi + KP - 1) / KP;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
 
   // Incremental pixel decode: (b, oy, ox) of this thread's row on the iterated grid (Hc x Wc per image), advanced by
   // exactly one chunk = step_img images + step_row rows + step_col columns (computed on the host; at most one carry
@@ -248,8 +235,8 @@ __global__ __launch_bounds__(256 * PS) void conv_wgrad_kernel(const WgradParams 
     constexpr int VPS = 32 / VE;  // 16-byte global vectors per 32-channel subtile
     auto woff = [&](int cv) { return (cv / VPS) * X3_SUB + (cv % VPS) * (VE * 2); };
     // fragment gather: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies row q, channels 4p..
-    const int lg = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
-    const int rd_lane = ((lg >> 1) * 8 + q) * 64 + ((lg & 1) * 16 + 4 * pq) * 2;  // + s*16*64 + h*4*64
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int rd_lane = ((grp >> 1) * 8 + q) * 64 + ((grp & 1) * 16 + 4 * pq) * 2;  // + s*16*64 + h*4*64
     const unsigned char* ya = lb + wm * X3_SUB + rd_lane;
     const unsigned char* xa = lb + X3_OP + wn * X3_SUB + rd_lane;
     auto frag = [&](const unsigned char* base, int pl, int s) {
@@ -342,21 +329,6 @@ __global__ __launch_bounds__(256 * PS) void conv_wgrad_kernel(const WgradParams 
     }
   }
 
-  if constexpr (PS > 1) {
-    // groups 1 .. PS-1 hand their accumulators to group 0 through the (now idle) staging LDS: element r of thread t at
-    // [(g-1)*4096 + r*256 + t] (conflict-free both ways), added in group order
-    static_assert(FM == 1 && FN == 1, "one 32x32 accumulator per wave");
-    if (grp > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lds_all[(grp - 1) * (BMW * BNW) + r * 256 + tid] = acc[0][0][r];
-    }
-    __syncthreads();
-    if (grp > 0) return;
-#pragma unroll
-    for (int g = 1; g < PS; ++g)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][0][r] += lds_all[(g - 1) * (BMW * BNW) + r * 256 + tid];
-  }
   // D[co][ci]: ci_l = lane&31, co_l = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int taps = p.slab_taps;
   float* __restrict__ slab = p.partial + (long)split * p.Cout * taps * Cin;
@@ -494,7 +466,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedu
 // (profiles/README.md): with ~1024 workgroups the 64x64 tile beats 128x128 on every wide layer by 15-20 % (fewer split
 // slabs to write and re-read, r01_h); a 32x32 tile over 128-pixel chunks (a quarter of the slab bytes) is much slower
 // (twice the L2 -> LDS staging per MFMA, r03)
-static inline dim3 block256() { return dim3(256); }
 static int pick_wtile(const WgradParams& p) { return (p.Cout > 32 && p.C0 + p.C1 > 32) ? 64 : 32; }
 static bool patch_wgrad_off() {
   static const bool off = getenv("D3F_NO_PATCH_WGRAD") != nullptr;  // debugging knob: the tap-parallel kernel everywhere
@@ -520,16 +491,6 @@ bool wgrad_class_applies(const WgradParams& p, int dtype) {
   return pick_wtile(p) == 64 && (p.C0 % 64) == 0 && (p.C1 % 64) == 0;
 }
 
-// pixel ranges per workgroup of the tap-parallel kernel (1 | 2 | 4; D3F_WGRAD_PS overrides for A/B runs)
-static int wgrad_ps_knob() {
-  static const int ps = [] {
-    const char* e = getenv("D3F_WGRAD_PS");
-    const int v = e ? atoi(e) : 2;
-    return v >= 4 ? 4 : v >= 2 ? 2 : 1;
-  }();
-  return ps;
-}
-
 int wgrad_plan(WgradParams& p, int dtype) {
   D3F_CHECK(dtype == D3F_F32 || dtype == D3F_BF16, "wgrad: bad dtype %d", dtype);
   const int ve = dtype == D3F_F32 ? 4 : 8;
@@ -553,7 +514,6 @@ int wgrad_plan(WgradParams& p, int dtype) {
   p.Hc = p.cls ? p.H0s : p.Ho;
   p.Wc = p.cls ? p.W0s : p.Wo;
   p.Mi = p.B * p.Hc * p.Wc;
-  p.ps = 1;
   p.patch = patch_wgrad_off() ? 0 : wgrad_patch_variant(p, dtype);
   if (p.part != WG_WHOLE) D3F_CHECK(wgrad_class_applies(p, dtype), "wgrad: class form does not apply to this layer");
   if (p.patch) {  // persistent patch kernel: one slab per workgroup column
@@ -574,20 +534,13 @@ int wgrad_plan(WgradParams& p, int dtype) {
   p.tiles_ci = cdiv(p.slab_cin, t);
   const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps;
   const int total_chunks = cdiv(p.Mi, KP);
-  const long target = 928;  // ~3.6 groups of 4 waves per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
+  const long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
   long splits = (target + base - 1) / base;
-  const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per pixel range
+  const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.chunks_per_split = cdiv(total_chunks, splits);
-  const int ranges = cdiv(total_chunks, p.chunks_per_split);
-  // in-CU reduction (round 5): PS pixel ranges per workgroup share one slab.  The wave count of the launch stays what the
-  // target above asks for; only the 64x64 tile's kernels carry the PS groups.
-  if (t == 64) {
-    const int want = std::min(wgrad_ps_knob(), dtype == D3F_BF16 ? 2 : 4);
-    while (p.ps < want && ranges >= 2 * p.ps) p.ps *= 2;
-  }
-  p.splits = cdiv(ranges, p.ps);
+  p.splits = cdiv(total_chunks, p.chunks_per_split);
   return 0;
 }
 
@@ -597,30 +550,19 @@ size_t wgrad_partial_floats(const WgradParams& p) {
 
 // (Wave slots, not priorities: these launches run at the lowest stream priority NEXT to the dependent BatchNorm ->
 // data-gradient chain; an occupancy cap through unused dynamic LDS was measured slower, profiles/README.md round 2.)
-template <typename T, int PS>
-static void wgrad_launch_64(const WgradParams& p, dim3 grid, hipStream_t stream, bool x3) {
-  const dim3 block(256 * PS);
-  if (x3 || sizeof(T) == 2) {  // f32x3, and bf16 storage on the native bf16 MFMA
-    if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, true, PS>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, false, PS>), grid, block, 0, stream, p);
-    return;
-  }
-  if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true, PS>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, false, PS>), grid, block, 0, stream, p);
-}
-
 template <typename T>
 static void wgrad_launch_t(const WgradParams& p, int bm, dim3 grid, hipStream_t stream, bool x3) {
+  const dim3 block(256);
   if (bm == 64) {
-    if (p.ps == 4) {
-      if constexpr (sizeof(T) == 4) wgrad_launch_64<T, 4>(p, grid, stream, x3);  // (bf16: LDS of 4 groups < 3 accumulator tiles)
-    } else if (p.ps == 2) {
-      wgrad_launch_64<T, 2>(p, grid, stream, x3);
-    } else {
-      wgrad_launch_64<T, 1>(p, grid, stream, x3);
+    if (x3 || sizeof(T) == 2) {  // f32x3, and bf16 storage on the native bf16 MFMA
+      if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, true>), grid, block, 0, stream, p);
+      return;
     }
+    if (p.cls) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64, 2, 2, 1, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block256(), 0, stream, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 32, 32, 1, 1, 4, false>), grid, block, 0, stream, p);
   }
 }
 
@@ -637,7 +579,6 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   const int t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1, "wgrad: params were not planned");
   D3F_CHECK(!p.cls || t == 64, "wgrad: class form needs the 64x64 tile");
-  D3F_CHECK(p.ps == 1 || ((p.ps == 2 || (p.ps == 4 && dtype != D3F_BF16)) && t == 64), "wgrad: %d pixel ranges per workgroup", p.ps);
   const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits);
   const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops, stream);

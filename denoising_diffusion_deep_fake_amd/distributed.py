@@ -105,9 +105,10 @@ class DataParallel:
     """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
 
     def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None, buckets=None):
-        """buckets: exchange buckets per backward pass (None = 4, one per engine segment; 2; 1; or explicit segment ranges --
-        Unet.set_grad_sync).  4 starts the first all-reduce earliest and leaves 5.4 MB behind the backward pass; every
-        bucket costs the dependent chain a cross-stream event pair (bench.py --dp-selftest prices both on one GPU)."""
+        """buckets: exchange buckets per backward pass (None = 4, one per engine segment; 2 = (head .. layer3) | (layer2 ..
+        stem); 1; or explicit segment ranges -- Unet.set_grad_sync).  4 starts the first all-reduce earliest; 2 and 4 both
+        leave only the last 5.4 MB behind the backward pass; every bucket costs the dependent chain cross-stream event
+        pairs (bench.py --dp-selftest prices 4 / 2 / 1 on one GPU: profiles/r05_dp_selftest.json)."""
         self.model, self.optimizer = model, optimizer
         self.buckets = buckets
         self.reducer = BucketAllReducer(group, compress=grad_compress)

@@ -392,9 +392,10 @@ class Unet(nn.Module):
         (data-parallel all-reduce overlap); None disables.
 
         buckets: how the engine's backward segments (4: head + decoder | layer4 | layer3 | layer2 .. stem, final in that
-        order) are grouped into exchange buckets -- None / 4: one bucket per segment; 2: (head .. layer4) | (layer3 .. stem);
-        1: one bucket = the whole gradient at the end of backward; or an explicit list of (first, end) segment ranges
-        that tile range(nseg) in order.  Every bucket costs the chain a cross-stream event pair and RCCL a launch; fewer
+        order) are grouped into exchange buckets -- None / 4: one bucket per segment; 2: (head .. layer3: 92 MB, final at
+        about two thirds of the backward pass) | (layer2 .. stem: 5.4 MB, the only bytes exchanged behind the backward
+        pass); 1: one bucket = the whole gradient at the end of backward; or an explicit list of (first, end) segment
+        ranges that tile range(nseg) in order.  Every bucket costs the chain a cross-stream event pair and RCCL a launch; fewer
         buckets expose more of the LAST bucket's all-reduce behind the backward pass."""
         self._rt["grad_sync"] = fn
         self._rt["grad_buckets"] = buckets
@@ -407,7 +408,7 @@ class Unet(nn.Module):
             if buckets == 1:
                 return [(0, nseg)]
             if buckets == 2 and nseg >= 2:
-                return [(0, nseg // 2), (nseg // 2, nseg)]
+                return [(0, nseg - 1), (nseg - 1, nseg)]
             raise D3FError(f"gradient buckets: {buckets} (the engine has {nseg} backward segments: 1, 2 or {nseg})")
         groups = [(int(b), int(e)) for b, e in buckets]
         if not groups or groups[0][0] != 0 or groups[-1][1] != nseg or any(b >= e for b, e in groups) or \

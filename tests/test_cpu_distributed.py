@@ -226,7 +226,7 @@ def test_gradient_bucket_groups():
     from denoising_diffusion_deep_fake_amd._lib import D3FError
     g = Unet._bucket_groups
     assert g(None, 4) == [(0, 1), (1, 2), (2, 3), (3, 4)] == g(4, 4)
-    assert g(2, 4) == [(0, 2), (2, 4)]
+    assert g(2, 4) == [(0, 3), (3, 4)]
     assert g(1, 4) == [(0, 4)]
     assert g([(0, 3), (3, 4)], 4) == [(0, 3), (3, 4)]
     for bad in (3, [(0, 2)], [(0, 2), (3, 4)], [(1, 4)], [(0, 2), (2, 2), (2, 4)]):
