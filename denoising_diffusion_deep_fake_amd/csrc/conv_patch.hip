@@ -45,23 +45,31 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   const bool wide = p.C0 == 32 && dtype == D3F_BF16 && p.mode != CONV_HEAD_NCHW;
 #endif
   const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
+  // ... and behind a nearest x2 up-sampling (forward only): <= 16 filters, even extents
+  const bool up = wide && p.shift0 == 1 && p.mode != CONV_DGRAD && p.Cout <= 16 && p.H0s * 2 == p.Hv && p.W0s * 2 == p.Wv;
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
-         p.shift0 == 0 && p.zi == 0 && p.Cout <= (wide ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
+         (p.shift0 == 0 || up) && p.zi == 0 && p.Cout <= (wide ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
          (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
 
-template <typename T, int CIN, int BN>
+// UP (bf16 x 32 channels -> <= 16 filters, round 5): the source is read through a nearest x2 up-sampling (decoder block 4
+// conv1 in bf16 storage, whose 32 channels are half a k-tile of the implicit GEMM: it gathered through the up-sampling
+// with the small-channel loader).  The patch is staged at the source's own LOW resolution -- 4 x 34 pixels for the 4 x 64
+// output tile -- and tap (kh, kw) of output pixel (y, x) reads low-resolution pixel ((y + kh - 1) >> 1, (x + kw - 1) >> 1):
+// the row is wave-uniform, the column one of three per-lane offsets made once.
+template <typename T, int CIN, int BN, bool UP = false>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
   constexpr bool BF = sizeof(T) == 2;
   // W64: bf16 x 32 channels -- 64-byte pixels, 32 filters (decoder block 3 conv2)
   constexpr bool W64 = BF && CIN == 32;
-  static_assert(((CIN == 16 || (CIN == 4 && !BF)) && BN == 16) || (W64 && BN == 32),
+  static_assert(!UP || (W64 && BN == 16), "up-sampled source: bf16 x 32 channels -> 16 filters");
+  static_assert(((CIN == 16 || (CIN == 4 && !BF)) && BN == 16) || (W64 && (BN == 32 || UP)),
                 "16 channels (forward / data gradient of decoder block 4, head forward), fp32 x 4 (data gradient of the "
                 "head) or bf16 x 32 -> 32 (decoder block 3 conv2)");
   constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte vector
-  constexpr int PH = CP_PH, PW = CP_PW, PR = PH + 2, PC = PW + 2;
+  constexpr int PH = CP_PH, PW = CP_PW, PR = UP ? PH / 2 + 2 : PH + 2, PC = UP ? PW / 2 + 2 : PW + 2;
   // dwords per staged pixel: such that the fragment reads spread over the banks (fp32 CIN 16: +4 pad, 16-byte reads;
   // CIN 4: stride 12, scalar reads; bf16: 32 B of channels + 8 B pad = 10 dwords -- 10 * row covers the even banks
   // over 16 rows, the 8-byte fragment reads are conflict-free; the staging stores are 8-byte halves)
@@ -95,9 +103,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
     const int id = tid + 256 * i;
     const int pix = id / CV, cv = id - pix * CV;
     const int pr = pix / PC, pc = pix - pr * PC;
-    const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-    const bool ok = id < NPV && (unsigned)gy < (unsigned)p.Hv && (unsigned)gx < (unsigned)p.Wv;
-    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * p.Hv + gy) * p.Wv + gx) * CIN + cv * VEC) * (unsigned)sizeof(T) : BUF_OOB);
+    // (UP: y0, x0 are even; low-resolution pixel -1 / H0s stands for the zero border of the up-sampled image)
+    const int gy = (UP ? y0 / 2 : y0) - 1 + pr, gx = (UP ? x0 / 2 : x0) - 1 + pc;
+    const int Hs = UP ? p.H0s : p.Hv, Ws = UP ? p.W0s : p.Wv;
+    const bool ok = id < NPV && (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
+    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * Hs + gy) * Ws + gx) * CIN + cv * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
 #pragma unroll
   for (int i = 0; i < NLW; ++i) {
@@ -143,7 +153,27 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   f32x4 acc[FM * NB];  // [fragment i][16-filter group j] at i * NB + j
 #pragma unroll
   for (int i = 0; i < FM * NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (W64) {
+  if constexpr (UP) {
+    // staged column of (x0 + 16 i + fr + kw - 1) >> 1 = ((fr + kw - 1) >> 1) + 1 + 8 i; staged row of (y0 + wave + kh - 1) >> 1
+    // = ((wave + kh - 1) >> 1) + 1
+    const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;
+    const float* Acol[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) Acol[kw] = P + (((fr + kw - 1) >> 1) + 1) * CS + fq * 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int prow = ((wave + kh - 1) >> 1) + 1;
+      const uint4 bb = *reinterpret_cast<const uint4*>(Bbase + tap * (CIN / 2));
+      uint4 a[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(Acol[kw] + (prow * PC + 8 * i) * CS);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[i]),
+                                                         *reinterpret_cast<const bf16x8*>(&bb), acc[i], 0, 0, 0);
+    }
+  } else if constexpr (W64) {
     // lane holds channels 8 fq .. 8 fq + 7 (16 bytes) of its pixel / filter: one MFMA contracts the tap's 32 channels
     const float* Abase = P + (wave * PC + fr) * CS + fq * 4;
     const float* Bbase = Wl + fr * WS + (fq ^ ((fr >> 1) & 3)) * 4;  // (rows fr and fr + 16 share the swizzle)
@@ -547,7 +577,8 @@ void conv_patch_plan(ConvParams& p, int dtype) {
     p.stat_rows = p.tiles_m;
     return;
   }
-  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? 4 : 3) : 1;  // 3 / 4: the bf16-storage instantiations (16 / 32 channels)
+  // 3 / 4 / 5: the bf16-storage instantiations (16 channels / 32 channels / 32 channels behind an up-sampling)
+  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? (p.shift0 ? 5 : 4) : 3) : 1;
   p.nz = 1;
   p.splitk = 1;
   p.w_ld = p.Kpad;
@@ -564,10 +595,12 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK((p.patch == 1 || p.patch == 3 || p.patch == 4) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
-                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && p.patch == 4)) && p.Cout <= (p.patch == 4 ? 32 : 16),
+  D3F_CHECK((p.patch == 1 || p.patch == 3 || p.patch == 4 || p.patch == 5) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
+                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && p.patch >= 4)) && p.Cout <= (p.patch == 4 ? 32 : 16) &&
+                (p.shift0 == 0) == (p.patch != 5),
             "conv: patch params were not planned");
-  if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);

@@ -35,6 +35,8 @@ CASES = [
     (2, 8, 64, 32, 0, 32, 3, 1, 1, False),        # conv_patch_kernel<bf16, 32, 32> (64-byte pixels, 16x16x32 bf16 MFMA): forward + data gradient
     (1, 12, 128, 32, 0, 16, 3, 1, 1, False),      # ... 16 of the 32 filter columns real
     (3, 4, 64, 32, 0, 24, 3, 1, 1, False),        # ... a ragged filter count, one tile row per image
+    (2, 8, 64, 32, 0, 16, 3, 1, 1, True),         # conv_patch_kernel<bf16, 32, 16, UP>: forward through the up-sampling from a low-resolution patch
+    (1, 12, 128, 32, 0, 8, 3, 1, 1, True),        # ... two tiles per row, 8 of 16 filter columns real
     (1, 32, 32, 128, 64, 64, 3, 1, 1, True),      # class-form weight gradient (WG_CLASS + WG_SKIP), bf16 MFMA
     (3, 12, 20, 128, 64, 128, 3, 1, 1, True),     # ... ragged class grid
 ]
