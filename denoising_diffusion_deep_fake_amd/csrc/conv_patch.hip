@@ -44,7 +44,9 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
 #else
   const bool wide = p.C0 == 32 && dtype == D3F_BF16 && p.mode != CONV_HEAD_NCHW;
 #endif
-  const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32);
+  // C0 == 8, bf16: the head's data gradient in bf16 storage (3 channels in one 16-byte vector), staged as 16 channels
+  const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32) ||
+                      (p.C0 == 8 && p.mode == CONV_DGRAD && dtype == D3F_BF16);
   // ... and behind a nearest x2 up-sampling (forward only): <= 16 filters, even extents
   const bool up = wide && p.shift0 == 1 && p.mode != CONV_DGRAD && p.Cout <= 16 && p.H0s * 2 == p.Hv && p.W0s * 2 == p.Wv;
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
@@ -58,13 +60,17 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
 // with the small-channel loader).  The patch is staged at the source's own LOW resolution -- 4 x 34 pixels for the 4 x 64
 // output tile -- and tap (kh, kw) of output pixel (y, x) reads low-resolution pixel ((y + kh - 1) >> 1, (x + kw - 1) >> 1):
 // the row is wave-uniform, the column one of three per-lane offsets made once.
-template <typename T, int CIN, int BN, bool UP = false>
+// CSRC < CIN (bf16 x 8 source channels staged as 16, round 5): the data gradient of the segmentation head in bf16 storage
+// (dY has 3 channels padded to one 16-byte vector of 8).  The source pixel and every tap of a weight row fill the first
+// half of their 16-channel LDS slot, the second half is zero: the k-loop is the 16-channel one unchanged.
+template <typename T, int CIN, int BN, bool UP = false, int CSRC = CIN>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
   constexpr bool BF = sizeof(T) == 2;
   // W64: bf16 x 32 channels -- 64-byte pixels, 32 filters (decoder block 3 conv2)
   constexpr bool W64 = BF && CIN == 32;
   static_assert(!UP || (W64 && BN == 16), "up-sampled source: bf16 x 32 channels -> 16 filters");
+  static_assert(CSRC == CIN || (BF && CIN == 16 && CSRC == 8 && !UP), "half-filled pixels: bf16, 8 of 16 channels");
   static_assert(((CIN == 16 || (CIN == 4 && !BF)) && BN == 16) || (W64 && (BN == 32 || UP)),
                 "16 channels (forward / data gradient of decoder block 4, head forward), fp32 x 4 (data gradient of the "
                 "head) or bf16 x 32 -> 32 (decoder block 3 conv2)");
@@ -78,9 +84,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   // dwords per staged weight row (fp32 CIN 16: no pad, 16-byte chunks XOR-swizzled by the row; CIN 4: +4 pad, no
   // swizzle; bf16: 72 dwords of taps + 2 = 74: the same stride-10-mod-32 pattern over the filter rows)
   constexpr int WS = W64 ? KR / 2 : BF ? KR / 2 + 2 : (CIN == 16 ? KR : KR + 4);
-  constexpr int CV = CIN / VEC;        // 16-byte vectors per pixel
+  constexpr int CV = CSRC / VEC;       // 16-byte vectors per source pixel
+  constexpr int KS = 9 * CSRC;         // k extent of a packed weight row in memory
   constexpr int NPV = PR * PC * CV;    // patch vectors
-  constexpr int NWV = BN * (KR / VEC); // weight vectors
+  constexpr int NWV = BN * (KS / VEC); // weight vectors
   constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
   constexpr int BM = PH * PW, LDC = BN + 4, FM = PW / 16, NB = BN / 16;
   constexpr int PATCH_DW = PR * PC * CS > BM * LDC ? PR * PC * CS : BM * LDC;  // the C tile aliases the patch
@@ -107,12 +114,12 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
     const int gy = (UP ? y0 / 2 : y0) - 1 + pr, gx = (UP ? x0 / 2 : x0) - 1 + pc;
     const int Hs = UP ? p.H0s : p.Hv, Ws = UP ? p.W0s : p.Wv;
     const bool ok = id < NPV && (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
-    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * Hs + gy) * Ws + gx) * CIN + cv * VEC) * (unsigned)sizeof(T) : BUF_OOB);
+    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * Hs + gy) * Ws + gx) * CSRC + cv * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
 #pragma unroll
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
-    const int row = id / (KR / VEC), ch = id - row * (KR / VEC);
+    const int row = id / (KS / VEC), ch = id - row * (KS / VEC);
     const bool ok = id < NWV && row < p.CoutPad;
     wv[i] = buf_load16(rw, ok ? (unsigned)(row * p.w_ld + ch * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
@@ -124,6 +131,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
       if constexpr (BF && !W64) {  // 40-byte pixels: two 8-byte stores
         *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4]) = make_uint2(pv[i].x, pv[i].y);
         *reinterpret_cast<uint2*>(&P[pix * CS + cv * 4 + 2]) = make_uint2(pv[i].z, pv[i].w);
+        if constexpr (CSRC < CIN) {  // channels 8 .. 15 of the slot: zero
+          *reinterpret_cast<uint2*>(&P[pix * CS + 4]) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(&P[pix * CS + 6]) = make_uint2(0u, 0u);
+        }
       } else {
         *reinterpret_cast<uint4*>(&P[pix * CS + cv * 4]) = pv[i];
       }
@@ -132,9 +143,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
-    const int row = id / (KR / VEC), ch = id - row * (KR / VEC);
+    const int row = id / (KS / VEC), ch = id - row * (KS / VEC);
     if (NWV % 256 == 0 || id < NWV) {
-      if constexpr (BF && !W64) {
+      if constexpr (CSRC < CIN) {  // vector `ch` = the 8 channels of tap `ch`: first half of the tap's 16-channel slot
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 8]) = make_uint2(wv[i].x, wv[i].y);
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 8 + 2]) = make_uint2(wv[i].z, wv[i].w);
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 8 + 4]) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 8 + 6]) = make_uint2(0u, 0u);
+      } else if constexpr (BF && !W64) {
         *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4]) = make_uint2(wv[i].x, wv[i].y);
         *reinterpret_cast<uint2*>(&Wl[row * WS + ch * 4 + 2]) = make_uint2(wv[i].z, wv[i].w);
       } else {
@@ -578,7 +594,8 @@ void conv_patch_plan(ConvParams& p, int dtype) {
     return;
   }
   // 3 / 4 / 5: the bf16-storage instantiations (16 channels / 32 channels / 32 channels behind an up-sampling)
-  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? (p.shift0 ? 5 : 4) : 3) : 1;
+  // 6: 8 source channels staged as 16 (the head's data gradient)
+  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? (p.shift0 ? 5 : 4) : p.C0 == 8 ? 6 : 3) : 1;
   p.nz = 1;
   p.splitk = 1;
   p.w_ld = p.Kpad;
@@ -595,11 +612,13 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK((p.patch == 1 || p.patch == 3 || p.patch == 4 || p.patch == 5) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
-                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && p.patch >= 4)) && p.Cout <= (p.patch == 4 ? 32 : 16) &&
+  D3F_CHECK((p.patch == 1 || (p.patch >= 3 && p.patch <= 6)) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
+                (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && (p.patch == 4 || p.patch == 5)) || (p.C0 == 8 && p.patch == 6)) &&
+                p.Cout <= (p.patch == 4 ? 32 : 16) &&
                 (p.shift0 == 0) == (p.patch != 5),
             "conv: patch params were not planned");
-  if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
