@@ -67,6 +67,7 @@ PROTOTYPES = {
     "d3f_unet_export": (_i, [_p, C.c_char_p, _p, _p, _p]),
     "d3f_unet_export_shape": (_i, [_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "d3f_conv_upsample_folded": (_i, [_i, _p]),
+    "d3f_conv_upsample_summed": (_i, [_i, _p]),
     "d3f_conv_packed_bytes": (_sz, [_i, _desc, _i]),
     "d3f_conv_pack_weights": (_i, [_i, _desc, _p, _p, _p, _p]),
     "d3f_conv_workspace_bytes": (_sz, [_i, _desc, _i]),

@@ -159,6 +159,9 @@ static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool a
   p.Ho = d->H; p.Wo = d->W;
   p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
   p.M = d->B * d->H * d->W;
+  // an up-sampled single source without folded weights: ask for the 2x2-summed gradient at the source's own resolution
+  // (kept by the plan only where a patch kernel serves it: d3f_conv_upsample_summed)
+  p.sum2 = (d->upsample0 && d->C1 == 0) ? 1 : 0;
   return conv_igemm_plan(p, dtype, allow_splitk);
 }
 
@@ -372,6 +375,12 @@ int d3f_conv_pack_weights(int dtype, const d3f_conv_desc* d, const float* w, voi
 }
 int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d) {
   return (d != nullptr && desc_check(dtype, d) == 0 && desc_upfold(dtype, d)) ? 1 : 0;
+}
+int d3f_conv_upsample_summed(int dtype, const d3f_conv_desc* d) {
+  ConvParams p;
+  if (d == nullptr || !d->upsample0 || desc_check(dtype, d) != 0 || desc_upfold(dtype, d)) return 0;
+  if (dgrad_params(dtype, d, p, false) != 0) return 0;
+  return p.sum2 ? 1 : 0;
 }
 size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
   ConvParams p;

@@ -194,6 +194,9 @@ struct ConvParams {
   // m -> (image, row, column) without integer divisions (filled by plan): q = umulhi(n, mul) >> shr for n < 2^31,
   // mul == 0 stands for a divisor of 1
   unsigned div_howo_mul, div_howo_shr, div_wo_mul, div_wo_shr;
+  int sum2;            // CONV_DGRAD request (set before the plan): store the 2x2 block sums of the gradient at HALF resolution
+                       // (the gradient w.r.t. a source that was read through the nearest x2 up-sampling); kept only when
+                       // a patch kernel takes the launch -- the plan clears it otherwise and the caller reduces itself
   int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
 };
 

@@ -1524,6 +1524,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
     conv_patch_plan(p, dtype);
     return 0;
   }
+  p.sum2 = 0;  // (a request the implicit GEMM does not serve: full-resolution output, the caller sums the 2x2 blocks)
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3, dtype == D3F_BF16);
   p.tiles_m = cdiv(p.M, t.BM);
   p.tiles_n = cdiv(p.Cout, t.BN);

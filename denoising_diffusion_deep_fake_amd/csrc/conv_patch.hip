@@ -49,8 +49,11 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
                       (p.C0 == 8 && p.mode == CONV_DGRAD && dtype == D3F_BF16);
   // ... and behind a nearest x2 up-sampling (forward only): <= 16 filters, even extents
   const bool up = wide && p.shift0 == 1 && p.mode != CONV_DGRAD && p.Cout <= 16 && p.H0s * 2 == p.Hv && p.W0s * 2 == p.Wv;
+  // a data gradient whose caller asked for the 2x2-summed (half-resolution) output: bf16 x 16 -> exactly 32 channels
+  const bool sum2 = p.sum2 && dtype == D3F_BF16 && p.mode == CONV_DGRAD && p.C0 == 16 && p.Cout == 32 && p.shift0 == 0;
+  if (p.sum2 && !sum2) return false;
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
-         (p.shift0 == 0 || up) && p.zi == 0 && p.Cout <= (wide ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
+         (p.shift0 == 0 || up) && p.zi == 0 && p.Cout <= (wide || sum2 ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
          (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
@@ -63,7 +66,12 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
 // CSRC < CIN (bf16 x 8 source channels staged as 16, round 5): the data gradient of the segmentation head in bf16 storage
 // (dY has 3 channels padded to one 16-byte vector of 8).  The source pixel and every tap of a weight row fill the first
 // half of their 16-channel LDS slot, the second half is zero: the k-loop is the 16-channel one unchanged.
-template <typename T, int CIN, int BN, bool UP = false, int CSRC = CIN>
+// SUM2 (bf16 x 16 -> 32, data gradient only, round 5): the data gradient of a convolution whose source was read through
+// the nearest x2 up-sampling WITHOUT the folded weights (decoder block 4 conv1 in bf16 storage).  The gradient w.r.t. the
+// low-resolution source is the 2x2 block sum of the full-resolution gradient: the epilogue adds the four pixels from the
+// fp32 C tile and stores at half resolution -- the full-resolution scratch tensor (67 MB written + read), the sum2x2
+// launch and the separate BatchNorm-backward reduce of the consumer (its partial sums ride in this epilogue) are gone.
+template <typename T, int CIN, int BN, bool UP = false, int CSRC = CIN, bool SUM2 = false>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   chain_priority();
   constexpr bool BF = sizeof(T) == 2;
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   constexpr bool W64 = BF && CIN == 32;
   static_assert(!UP || (W64 && BN == 16), "up-sampled source: bf16 x 32 channels -> 16 filters");
   static_assert(CSRC == CIN || (BF && CIN == 16 && CSRC == 8 && !UP), "half-filled pixels: bf16, 8 of 16 channels");
-  static_assert(((CIN == 16 || (CIN == 4 && !BF)) && BN == 16) || (W64 && (BN == 32 || UP)),
+  static_assert(!SUM2 || (BF && CIN == 16 && CSRC == 16 && BN == 32 && !UP), "2x2-summed data gradient: bf16 x 16 -> 32");
+  static_assert(((CIN == 16 || (CIN == 4 && !BF)) && (BN == 16 || SUM2)) || (W64 && (BN == 32 || UP)),
                 "16 channels (forward / data gradient of decoder block 4, head forward), fp32 x 4 (data gradient of the "
                 "head) or bf16 x 32 -> 32 (decoder block 3 conv2)");
   constexpr int VEC = 16 / (int)sizeof(T);  // elements per 16-byte vector
@@ -217,11 +226,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - kh * 3;
-      const v4s bb = *reinterpret_cast<const v4s*>(Bbase + tap * (CIN / 2));
+      v4s bb[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bb[j] = *reinterpret_cast<const v4s*>(Bbase + j * 16 * WS + tap * (CIN / 2));
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const v4s a = *reinterpret_cast<const v4s*>(Abase + ((kh * PC + kw) + i * 16) * CS);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bb, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bb[j], acc[i * NB + j], 0, 0, 0);
       }
     }
   } else if constexpr (CIN == 16) {
@@ -287,6 +299,79 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cs[(wave * PW + i * 16 + 4 * fq + r) * LDC + j * 16 + fr] = acc[i * NB + j][r];
   __syncthreads();
+
+  if constexpr (SUM2) {
+    // out[(b, y0/2 + lr, x0/2 + lc)][n] = sum of the 2x2 block of the C tile; thread -> channel vector cv of low-resolution
+    // pixels lp = tid / 8 + 32 i (i = 0, 1: the tile's two low-resolution rows)
+    constexpr int VN2 = BN / 4, LW = PW / 2, NLOW = (PH / 2) * LW, NV2 = NLOW * VN2 / 256, RS2 = 256 / VN2;
+    static_assert(NV2 * 256 == NLOW * VN2, "whole vectors per thread");
+    const int cv = tid % VN2, lp0 = tid / VN2;
+    const int n = cv * 4, C = p.Cout;
+    const int Hl = p.Ho / 2, Wl2 = p.Wo / 2;
+    T* __restrict__ o0 = reinterpret_cast<T*>(p.out0);
+    float4 v[NV2];
+    long mlow[NV2];
+#pragma unroll
+    for (int i = 0; i < NV2; ++i) {
+      const int lp = lp0 + i * RS2, lr = lp / LW, lc = lp - lr * LW;
+      const float* c00 = &Cs[((2 * lr) * PW + 2 * lc) * LDC + n];
+      const float4 a = *reinterpret_cast<const float4*>(c00), b2 = *reinterpret_cast<const float4*>(c00 + LDC);
+      const float4 c = *reinterpret_cast<const float4*>(c00 + PW * LDC), d = *reinterpret_cast<const float4*>(c00 + PW * LDC + LDC);
+      v[i] = make_float4((a.x + b2.x) + (c.x + d.x), (a.y + b2.y) + (c.y + d.y), (a.z + b2.z) + (c.z + d.z), (a.w + b2.w) + (c.w + d.w));
+      mlow[i] = ((long)b * Hl + (y0 / 2 + lr)) * Wl2 + (x0 / 2 + lc);
+      T* dst = o0 + mlow[i] * C + n;
+      if (p.acc0) {
+        const float4 o = ld4<T>(dst);
+        v[i].x += o.x; v[i].y += o.y; v[i].z += o.z; v[i].w += o.w;
+      }
+      st4<T>(dst, v[i]);
+    }
+    if (p.bn_partial != nullptr) {
+      // fused BatchNorm-backward reduction of the consuming layer over this tile's 64 low-resolution pixels
+      const T* __restrict__ yb = reinterpret_cast<const T*>(p.bn_y);
+      const T* __restrict__ ab = reinterpret_cast<const T*>(p.bn_a);
+      const float4 mu = *reinterpret_cast<const float4*>(p.bn_coef + n), is = *reinterpret_cast<const float4*>(p.bn_coef + C + n);
+      const float4 sc = *reinterpret_cast<const float4*>(p.bn_coef + 2 * C + n), sf = *reinterpret_cast<const float4*>(p.bn_coef + 3 * C + n);
+      const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+      const float c4[4] = {sc.x, sc.y, sc.z, sc.w}, f4[4] = {sf.x, sf.y, sf.z, sf.w};
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NV2; ++i) {
+        const float4 yv = ld4<T>(yb + mlow[i] * C + n);
+        const float4 av = ab != nullptr ? ld4<T>(ab + mlow[i] * C + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, aa[4] = {av.x, av.y, av.z, av.w};
+        const float gg[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float keep = ab != nullptr ? aa[k] : yy[k] * c4[k] + f4[k];
+          const float g = keep > 0.f ? gg[k] : 0.f;
+          s1[k] += g;
+          s2[k] += g * ((yy[k] - m4[k]) * i4[k]);
+        }
+      }
+      __syncthreads();  // all reads of the C tile are done
+      float* red = lds;  // [RS2][BN][2]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[(lp0 * BN + n + k) * 2 + 0] = s1[k];
+        red[(lp0 * BN + n + k) * 2 + 1] = s2[k];
+      }
+      __syncthreads();
+      if (tid < BN) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < RS2; ++g) {
+          a1 += red[(g * BN + tid) * 2 + 0];
+          a2 += red[(g * BN + tid) * 2 + 1];
+        }
+        if (tid < C) {
+          p.bn_partial[((long)tile * C + tid) * 2 + 0] = a1;
+          p.bn_partial[((long)tile * C + tid) * 2 + 1] = a2;
+        }
+      }
+    }
+    return;
+  }
 
   constexpr int VN = BN / 4, NVEC = BM * VN / 256, RSTEP = 256 / VN;
   const int cv = tid % VN, rv0 = tid / VN;
@@ -595,7 +680,8 @@ void conv_patch_plan(ConvParams& p, int dtype) {
   }
   // 3 / 4 / 5: the bf16-storage instantiations (16 channels / 32 channels / 32 channels behind an up-sampling)
   // 6: 8 source channels staged as 16 (the head's data gradient)
-  p.patch = dtype == D3F_BF16 ? (p.C0 == 32 ? (p.shift0 ? 5 : 4) : p.C0 == 8 ? 6 : 3) : 1;
+  // 7: 16 -> 32 channels with the 2x2-summed epilogue (ConvParams::sum2)
+  p.patch = dtype == D3F_BF16 ? (p.sum2 ? 7 : p.C0 == 32 ? (p.shift0 ? 5 : 4) : p.C0 == 8 ? 6 : 3) : 1;
   p.nz = 1;
   p.splitk = 1;
   p.w_ld = p.Kpad;
@@ -612,12 +698,13 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  D3F_CHECK((p.patch == 1 || (p.patch >= 3 && p.patch <= 6)) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
+  D3F_CHECK((p.patch == 1 || (p.patch >= 3 && p.patch <= 7)) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
                 (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && (p.patch == 4 || p.patch == 5)) || (p.C0 == 8 && p.patch == 6)) &&
-                p.Cout <= (p.patch == 4 ? 32 : 16) &&
+                p.Cout <= (p.patch == 4 || p.patch == 7 ? 32 : 16) && (p.sum2 != 0) == (p.patch == 7) &&
                 (p.shift0 == 0) == (p.patch != 5),
             "conv: patch params were not planned");
-  if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  if (p.patch == 7) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 32, false, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);

@@ -267,12 +267,16 @@ int UnetEngine::plan_unit(Unit& u) {
       d.Ho = u.Hv; d.Wo = u.Wv;
       d.KH = u.KH; d.KW = u.KW; d.stride = 1; d.pad = u.KH - 1 - u.pad;
       d.M = B * u.Hv * u.Wv;
+      // a source read through the up-sampling without folded weights (bf16: decoder block 4 conv1): ask for the gradient
+      // at the source's own resolution, 2x2 blocks summed in the epilogue; the plan keeps the request only when a patch
+      // kernel takes the launch (conv_patch.hip), otherwise full-resolution scratch + sum2x2 as before
+      d.sum2 = (u.up0 && u.C1 == 0) ? 1 : 0;
     }
     if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
     if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
     d.flops = 2.0 * macs;
     bwd_flops += 2.0 * macs;
-    if (u.up0) {
+    if (u.up0 && !d.sum2) {
       const size_t fb = (size_t)d.M * u.C0 * esize();
       if (fb > dfull_bytes) dfull_bytes = fb;
     }
@@ -375,7 +379,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
         op.dst0 = grad_dst(u.in0, &op.acc0);
         if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
         D3F_CHECK(u.segment == 0, "plan: unit %s: a folded up-sampling layer outside the decoder bucket", u.conv_name.c_str());
-      } else if (u.up0) {
+      } else if (u.up0 && !u.dgrad.sum2) {
         op.dst0_is_full_scratch = true;
         if (u.in1 >= 0) op.dst1 = grad_dst(u.in1, &op.acc1);
       } else {
@@ -383,7 +387,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       }
     }
     bwd_ops.push_back(op);
-    if (u.need_dgrad && u.up0 && !u.upfold) {
+    if (u.need_dgrad && u.up0 && !u.upfold && !u.dgrad.sum2) {
       BwdOp s;
       s.kind = BW_SUM2X2; s.unit = ui; s.C = u.C0; s.Hl = u.Hv / 2; s.Wl = u.Wv / 2; s.segment = u.segment;
       bool acc;
@@ -453,7 +457,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
       for (size_t k = j + 1; k < bwd_ops.size(); ++k) last = last && !writes(bwd_ops[k], pj.dst0);
       const Unit& uc = units[ck.unit];
       if (!last || !(uc.bn && ck.mask)) continue;
-      D3F_CHECK(pd.Cout == uc.Cout && pd.M == B * uc.Ho * uc.Wo && pd.out_c0 == pd.Cout,
+      D3F_CHECK(pd.Cout == uc.Cout && pd.M == (pd.sum2 ? 4 : 1) * B * uc.Ho * uc.Wo && pd.out_c0 == pd.Cout,
                 "plan: fused BatchNorm reduce shape mismatch (%s -> %s)", up.conv_name.c_str(), uc.conv_name.c_str());
       pj.fuse_for_unit = ck.unit;
       ck.fused_rows = pd.splitk > 1 ? pd.stat_rows : pd.tiles_m;

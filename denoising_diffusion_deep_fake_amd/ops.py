@@ -118,6 +118,8 @@ def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc
     dev = _dev(dy)
     ws = _conv_ws(d, dtype, 1, dev, splitk)
     folded = bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))
+    # ... or summed 2x2 in the launch's own epilogue (the patch form of the bf16 16 -> 32 layer): low resolution too
+    folded = folded or (bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_summed(dtype, C.byref(d))))
     low = (d.B, d.H // 2, d.W // 2, d.C0)
     if d.upsample0 and not folded:
         if acc0 or dx0 is not None:

@@ -209,8 +209,12 @@ int d3f_conv_winograd_forward(const d3f_conv_desc* d, const void* src0, const vo
  * overwriting.  With upsample0, dx0 is the gradient of the LOW-resolution source [B][H/2][W/2][C0] when the layer
  * runs with the up-sampling folded into pre-summed weights (d3f_conv_upsample_folded() == 1: 3x3, stride 1, pad 1,
  * whole k-tiles per tap -- every decoder layer of the network), else the full-resolution [B][H][W][C0] gradient of
- * the up-sampled operand, to be reduced with d3f_upsample2x_backward. */
+ * the up-sampled operand, to be reduced with d3f_upsample2x_backward -- unless d3f_conv_upsample_summed() == 1 (bf16
+ * storage, 16 -> 32 channels, one source: decoder.blocks.4.conv1 of smp's UnetDecoder, the F.interpolate + conv2d pair
+ * under d3f/train_denoiser/lit_module.py:117): the launch then sums the 2x2 blocks in its epilogue and dx0 is the
+ * LOW-resolution gradient as in the folded case. */
 int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d);
+int d3f_conv_upsample_summed(int dtype, const d3f_conv_desc* d);
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,
                            void* dx0, void* dx1, int acc0, int acc1, void* workspace, void* stream);
 /* dw in torch layout [Cout][CinReal][KH][KW] f32 */
