@@ -63,9 +63,10 @@ def parse():
                          "Bit-identical to the eager step, and SLOWER on this ROCm (measured r03: bf16 4.6 -> 10.9 ms, "
                          "128x128 3.8 -> 11.5 ms per step: a replayed graph whose nodes span three captured streams costs "
                          "~30 us per node; captured on one stream it equals the eager single-stream step) -- off by default")
-    ap.add_argument("--dp-buckets", type=int, default=4, choices=[1, 2, 4],
-                    help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 4 = one per "
-                         "engine segment (default), 2 = (head .. layer3) | (layer2 .. stem), 1 = one all-reduce at the end")
+    ap.add_argument("--dp-buckets", type=int, default=2, choices=[1, 2, 4],
+                    help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 2 = (head .. "
+                         "layer3) | (layer2 .. stem) (default: 1.3 %% machinery tax on one GPU against 3.2 %% for 4), 4 = one "
+                         "per engine segment, 1 = one all-reduce at the end")
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "180")),
                     help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
                          "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")

@@ -104,11 +104,13 @@ class BucketAllReducer:
 class DataParallel:
     """attach(model, optimizer): broadcast rank 0's parameters, overlap gradient all-reduce with backward."""
 
-    def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None, buckets=None):
-        """buckets: exchange buckets per backward pass (None = 4, one per engine segment; 2 = (head .. layer3) | (layer2 ..
-        stem); 1; or explicit segment ranges -- Unet.set_grad_sync).  4 starts the first all-reduce earliest; 2 and 4 both
-        leave only the last 5.4 MB behind the backward pass; every bucket costs the dependent chain cross-stream event
-        pairs (bench.py --dp-selftest prices 4 / 2 / 1 on one GPU: profiles/r05_dp_selftest.json)."""
+    def __init__(self, model, optimizer, group=None, sync_batchnorm=False, grad_compress=None, buckets=2):
+        """buckets: exchange buckets per backward pass (2 = (head .. layer3: 92 MB) | (layer2 .. stem: 5.4 MB), the default;
+        4 = one per engine segment; 1; or explicit segment ranges -- Unet.set_grad_sync).  2 and 4 both leave only the last
+        5.4 MB behind the backward pass; 4 starts the first all-reduce earlier, but every bucket costs the dependent chain
+        cross-stream event pairs whether or not bytes move: on one GPU over single-rank RCCL 4 buckets tax the step by 3.2 %,
+        2 by 1.3 %, 1 by 0.6 % (bench.py --dp-selftest, profiles/r05_dp_selftest.json).  The 92 MB bucket is final at about
+        two thirds of the backward pass and has ~1.5 ms of it left to hide in (0.54 ms at a ring bus bandwidth of 300 GB/s)."""
         self.model, self.optimizer = model, optimizer
         self.buckets = buckets
         self.reducer = BucketAllReducer(group, compress=grad_compress)

@@ -224,7 +224,7 @@ class Trainer:
         self.limit_val_batches = limit_val_batches
         self.sync_batchnorm = sync_batchnorm  # Lightning's flag: BatchNorm statistics over all ranks (default: per GPU)
         # data parallel only (no Lightning counterpart; distributed.DataParallel): exchange buckets per backward pass
-        # (None = 4) and "bf16" to send the gradient buckets as bfloat16 over xGMI
+        # (None = DataParallel's default, 2) and "bf16" to send the gradient buckets as bfloat16 over xGMI
         self.grad_buckets, self.grad_compress = grad_buckets, grad_compress
         self.global_step = 0
         self.current_epoch = 0
@@ -354,8 +354,8 @@ class Trainer:
         for opt in self.optimizers:
             mod = getattr(opt, "module", None)
             if mod is not None:
-                dist_utils.DataParallel(mod, opt, sync_batchnorm=self.sync_batchnorm, buckets=self.grad_buckets,
-                                        grad_compress=self.grad_compress)
+                dist_utils.DataParallel(mod, opt, sync_batchnorm=self.sync_batchnorm, grad_compress=self.grad_compress,
+                                        **({} if self.grad_buckets is None else {"buckets": self.grad_buckets}))
         takes_idx = "optimizer_idx" in inspect.signature(model.training_step).parameters
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in self.optimizers]
         # independent optimizer steps on their own streams (the module decides: LitModule.optimizer_streams)
