@@ -79,7 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
         hyper = self._hyper()
-        if lo % 4 or hi % 4:
+        if lo % 4 or (hi % 4 and hi != flat.numel()):  # (every slice handed to d3f_adam_step must START on a 16-byte boundary)
             raise RuntimeError(f"FusedAdam(overlap_tail=True): bucket range [{lo}, {hi}) is not on 16-byte boundaries")
         ops.adam_step(flat[lo:hi], grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], hyper[0], hyper[1], hyper[2],
                       hyper[3], self._step + 1, hyper[4])
