@@ -53,7 +53,7 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   const bool sum2 = p.sum2 && dtype == D3F_BF16 && p.mode == CONV_DGRAD && p.C0 == 16 && p.Cout == 32 && p.shift0 == 0;
   if (p.sum2 && !sum2) return false;
   return mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.C1 == 0 &&
-         (p.shift0 == 0 || up) && p.zi == 0 && p.Cout <= (wide || sum2 ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
+         (p.shift0 == 0 || up) && p.zi == 0 && p.Cout <= (wide && !up ? 64 : sum2 ? 32 : 16) && (p.mode == CONV_HEAD_NCHW || (p.Cout % 4) == 0) &&
          p.Hv == p.Ho && p.Wv == p.Wo && (p.Ho % CP_PH) == 0 &&
          (p.Wo % CP_PW) == 0 && p.Kpad >= 9 * p.C0;
 }
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   const int tile = (int)blockIdx.x;
   const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
   const int y0 = ty * PH, x0 = tx * PW;
+  const int n0 = (int)blockIdx.y * BN;  // first filter of this workgroup (grid.y > 1: the 64-filter bf16 launches)
 
   // ---- stage the patch and the weights (all loads in flight, then the LDS writes) ----------------------------------
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.src0, p.src0_bytes);
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
   for (int i = 0; i < NLW; ++i) {
     const int id = tid + 256 * i;
     const int row = id / (KS / VEC), ch = id - row * (KS / VEC);
-    const bool ok = id < NWV && row < p.CoutPad;
-    wv[i] = buf_load16(rw, ok ? (unsigned)(row * p.w_ld + ch * VEC) * (unsigned)sizeof(T) : BUF_OOB);
+    const bool ok = id < NWV && n0 + row < p.CoutPad;
+    wv[i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.w_ld + ch * VEC) * (unsigned)sizeof(T) : BUF_OOB);
   }
 #pragma unroll
   for (int i = 0; i < NLP; ++i) {
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
 
   constexpr int VN = BN / 4, NVEC = BM * VN / 256, RSTEP = 256 / VN;
   const int cv = tid % VN, rv0 = tid / VN;
-  const int n = cv * 4;
+  const int n = n0 + cv * 4;
   const bool n_ok = n < p.Cout;
   // tile row -> output pixel index
   auto out_row = [&](int row) { return mrow0 + (long)(row / PW) * p.Wo + (row % PW); };
@@ -410,9 +411,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
           a1 += red[(g * BN + tid) * 2 + 0];
           a2 += red[(g * BN + tid) * 2 + 1];
         }
-        if (tid < p.CoutPad) {
-          p.stats[((long)tile * p.CoutPad + tid) * 2 + 0] = a1;
-          p.stats[((long)tile * p.CoutPad + tid) * 2 + 1] = a2;
+        if (n0 + tid < p.CoutPad) {
+          p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 0] = a1;
+          p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 1] = a2;
         }
       }
     }
@@ -493,9 +494,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
           a1 += red[(g * BN + tid) * 2 + 0];
           a2 += red[(g * BN + tid) * 2 + 1];
         }
-        if (tid < C) {
-          p.bn_partial[((long)tile * C + tid) * 2 + 0] = a1;
-          p.bn_partial[((long)tile * C + tid) * 2 + 1] = a2;
+        if (n0 + tid < C) {
+          p.bn_partial[((long)tile * C + n0 + tid) * 2 + 0] = a1;
+          p.bn_partial[((long)tile * C + n0 + tid) * 2 + 1] = a2;
         }
       }
     }
@@ -686,7 +687,7 @@ void conv_patch_plan(ConvParams& p, int dtype) {
   p.splitk = 1;
   p.w_ld = p.Kpad;
   p.tiles_m = p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW);
-  p.tiles_n = 1;
+  p.tiles_n = p.patch == 4 ? cdiv(p.Cout, 32) : 1;  // 64 filters: two 32-filter workgroups per tile (grid.y), each stages the patch
   p.stat_rows = p.tiles_m;
 }
 
@@ -700,13 +701,14 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
   }
   D3F_CHECK((p.patch == 1 || (p.patch >= 3 && p.patch <= 7)) && p.tiles_m == p.B * (p.Ho / CP_PH) * (p.Wo / CP_PW) &&
                 (p.C0 == 16 || (p.C0 == 4 && p.patch == 1) || (p.C0 == 32 && (p.patch == 4 || p.patch == 5)) || (p.C0 == 8 && p.patch == 6)) &&
-                p.Cout <= (p.patch == 4 || p.patch == 7 ? 32 : 16) && (p.sum2 != 0) == (p.patch == 7) &&
+                p.Cout <= (p.patch == 4 ? 64 : p.patch == 7 ? 32 : 16) && (p.sum2 != 0) == (p.patch == 7) &&
+                p.tiles_n == (p.patch == 4 ? cdiv(p.Cout, 32) : 1) &&
                 (p.shift0 == 0) == (p.patch != 5),
             "conv: patch params were not planned");
   if (p.patch == 7) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 32, false, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
   else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
