@@ -91,7 +91,7 @@ static int fwd_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool all
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
   std::memset(&p, 0, sizeof(p));
-  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = d->C0; p.C1 = d->C1;
+  p.B = d->B; p.Hv = d->H; p.Wv = d->W; p.C0 = d->C0; p.C1 = d->C1; p.cin_real = d->CinReal;
   p.shift0 = d->upsample0 ? 1 : 0;
   p.H0s = d->H >> p.shift0; p.W0s = d->W >> p.shift0;
   p.Ho = g.Ho; p.Wo = g.Wo; p.Cout = d->Cout; p.CoutPad = g.CoutPad; p.Kpad = g.Kpad;

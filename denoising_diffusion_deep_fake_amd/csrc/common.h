@@ -194,6 +194,8 @@ struct ConvParams {
   // m -> (image, row, column) without integer divisions (filled by plan): q = umulhi(n, mul) >> shr for n < 2^31,
   // mul == 0 stands for a divisor of 1
   unsigned div_howo_mul, div_howo_shr, div_wo_mul, div_wo_shr;
+  int cin_real;        // forward launches: real (unpadded) input channels when the caller knows them (the packed weights of
+                       // the channels beyond are zero), else 0; lets the bf16 stem kernel stage 4 of its 8 channels
   int sum2;            // CONV_DGRAD request (set before the plan): store the 2x2 block sums of the gradient at HALF resolution
                        // (the gradient w.r.t. a source that was read through the nearest x2 up-sampling); kept only when
                        // a patch kernel takes the launch -- the plan clears it otherwise and the caller reduces itself
@@ -232,6 +234,7 @@ int conv_winograd_pack_launch(const float* w /*[Cout][Cin][3][3]*/, float* u, in
 int conv_winograd_launch(const ConvParams& p /*w = U*/, hipStream_t stream);
 bool conv_patch_applies(const ConvParams& p, int dtype);
 bool conv_stem_applies(const ConvParams& p, int dtype);  // encoder.conv1 (7x7 stride 2, 4 staged channels)
+bool conv_stem_bf16_applies(const ConvParams& p, int dtype);  // ... in bf16 storage (one 16-byte vector per pixel)
 void conv_patch_plan(ConvParams& p, int dtype);
 int conv_patch_launch(const ConvParams& p, hipStream_t stream);
 

@@ -1520,7 +1520,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   D3F_CHECK(b0 < (1L << 31) && b1 < (1L << 31) && bw < (1L << 31), "conv: operand larger than 2 GiB");
   p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
   p.patch = 0;
-  if (conv_patch_applies(p, dtype) || conv_stem_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
+  if (conv_patch_applies(p, dtype) || conv_stem_applies(p, dtype) || conv_stem_bf16_applies(p, dtype)) {  // full-resolution 16-channel 3x3 layers: LDS-patch kernel (conv_patch.hip)
     conv_patch_plan(p, dtype);
     return 0;
   }

@@ -667,10 +667,181 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// encoder.conv1 in bf16 storage (round 5): the image's 3 channels arrive padded to one 16-byte vector of 8 bf16, i.e.
+// a quarter of a k-tile per tap -- the implicit GEMM ran it with the small-channel loader at 69 us (99 us next to the
+// weight packing) for 2 us of matrix work.  Same tiling as conv_stem_kernel (8 x 32 output pixels x 32 filters), but:
+//   patch: 21 x 69 pixels x 4 channels (the first 8 bytes of every pixel; channel 3 is the zero pad), row-major, 8 bytes
+//     per pixel -- output pixel ox reads input columns 2 ox + kw, so taps (kw, kw + 1) of lane ox are 16 contiguous bytes
+//     and the 32 lanes of a fragment read 512 contiguous bytes (conflict-free);
+//   weights: [32][7 rows][8 tap slots][4 ch] bf16 (+16 B per filter), slot 7 zero;
+//   k-loop: v_mfma_f32_32x32x16_bf16 contracts FOUR taps x 4 channels per instruction (lane group g supplies taps
+//     4 j + 2 g, 4 j + 2 g + 1): 7 x 2 instructions per 32 x 32 fragment.
+// LDS 36.9 KB (the fp32 C tile aliases patch + weights) -> 4 workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+bool conv_stem_bf16_applies(const ConvParams& p, int dtype) {
+  if (patch_conv_off() || dtype != D3F_BF16) return false;
+#ifdef D3F_NO_PATCH32
+  return false;
+#endif
+  const bool mode_ok = (p.mode == CONV_RAW_STATS) || (p.mode == CONV_EVAL_FUSED && p.res == nullptr);
+  // (cin_real in 1 .. 4: the packed weights of channels 4 .. 7 are zero, so only the first half of a pixel is staged)
+  return mode_ok && p.par == 0 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.C0 == 8 && p.C1 == 0 &&
+         p.cin_real >= 1 && p.cin_real <= 4 &&
+         p.shift0 == 0 && p.zi == 0 && (p.Cout % ST_BN) == 0 && p.Hv == 2 * p.Ho && p.Wv == 2 * p.Wo &&
+         (p.Ho % ST_PH) == 0 && (p.Wo % ST_PW) == 0 && p.Kpad >= 49 * 8;
+}
+
+__global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const ConvParams p) {
+  chain_priority();
+  constexpr int PH = ST_PH, PW = ST_PW, BN = ST_BN;
+  constexpr int PR = 2 * PH + 5, PC = 2 * PW + 5;   // 21 x 69 input pixels
+  constexpr int PCS = PC + 3;                       // staged row: 72 pixels of 8 bytes (the last tap pair of a row reads one past)
+  constexpr int PATCH_DW = PR * PCS * 2 + 4;
+  constexpr int WS = 7 * 8 * 2 + 4;                 // dwords per staged filter: 56 tap slots x 8 bytes + 16 bytes
+  constexpr int NPV = PR * PC, NWV = BN * 49;
+  constexpr int NLP = (NPV + 255) / 256, NLW = (NWV + 255) / 256;
+  constexpr int BM = PH * PW, LDC = BN + 4;
+  constexpr int LDS_DW = BM * LDC > PATCH_DW + BN * WS ? BM * LDC : PATCH_DW + BN * WS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_DW];
+  float* P = lds;
+  float* Wl = lds + PATCH_DW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = p.Wo / PW, tiles_y = p.Ho / PH;
+  const int tile = (int)blockIdx.x, n0 = (int)blockIdx.y * BN;
+  const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+  const int y0 = ty * PH, x0 = tx * PW;
+
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.src0, p.src0_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+  uint4 pv[NLP], wv[NLW];
+#pragma unroll
+  for (int i = 0; i < NLP; ++i) {
+    const int id = tid + 256 * i;
+    const int pr = id / PC, pc = id - pr * PC;
+    const int gy = 2 * y0 - 3 + pr, gx = 2 * x0 - 3 + pc;
+    const bool ok = id < NPV && (unsigned)gy < (unsigned)p.Hv && (unsigned)gx < (unsigned)p.Wv;
+    pv[i] = buf_load16(rs, ok ? (unsigned)(((b * p.Hv + gy) * p.Wv + gx) * 8) * 2u : BUF_OOB);
+  }
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    const int id = tid + 256 * i;  // (filter, tap)
+    const int n = id / 49, t = id - n * 49;
+    const bool ok = id < NWV && (n0 + n) < p.CoutPad;
+    wv[i] = buf_load16(rw, ok ? (unsigned)((n0 + n) * p.w_ld + t * 8) * 2u : BUF_OOB);
+  }
+  // zero what no load writes: pixels 69..71 of every staged row, tap slot 7 of every filter row
+  for (int id = tid; id < PR * 3; id += 256) {
+    const int pr = id / 3, pc = PC + id - pr * 3;
+    *reinterpret_cast<uint2*>(&P[(pr * PCS + pc) * 2]) = make_uint2(0u, 0u);
+  }
+  for (int id = tid; id < BN * 7; id += 256) {
+    const int n = id / 7, kh = id - n * 7;
+    *reinterpret_cast<uint2*>(&Wl[n * WS + (kh * 8 + 7) * 2]) = make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < NLP; ++i) {
+    const int id = tid + 256 * i;
+    const int pr = id / PC, pc = id - pr * PC;
+    if (id < NPV) *reinterpret_cast<uint2*>(&P[(pr * PCS + pc) * 2]) = make_uint2(pv[i].x, pv[i].y);
+  }
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    const int id = tid + 256 * i;
+    const int n = id / 49, t = id - n * 49, kh = t / 7, kw = t - kh * 7;
+    if (id < NWV) *reinterpret_cast<uint2*>(&Wl[n * WS + (kh * 8 + kw) * 2]) = make_uint2(wv[i].x, wv[i].y);
+  }
+  __syncthreads();
+
+  // lane: output pixel fr of its fragment, k group fq = taps (4 j + 2 fq, 4 j + 2 fq + 1) x 4 channels
+  const int fr = lane & 31, fq = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // fragment i = tile row 2 * wave + i: input row 2 * (2 * wave + i) + kh, input column 2 * fr + kw
+  const float* Abase = P + ((4 * wave) * PCS + 2 * fr + 2 * fq) * 2;
+  const float* Bbase = Wl + fr * WS + (2 * fq) * 2;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 bb = *reinterpret_cast<const uint4*>(Bbase + (kh * 8 + 4 * j) * 2);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 a = *reinterpret_cast<const uint4*>(Abase + ((2 * i + kh) * PCS + 4 * j) * 2);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                         *reinterpret_cast<const bf16x8*>(&bb), acc[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: register r of fragment i = out[pixel (y0 + 2*wave + i, x0 + (r&3) + 8*(r>>2) + 4*fq)][n0 + fr]
+  __syncthreads();
+  float* Cs = lds;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Cs[((2 * wave + i) * PW + (r & 3) + 8 * (r >> 2) + 4 * fq) * LDC + fr] = acc[i][r];
+  __syncthreads();
+
+  constexpr int VN = BN / 4, NVEC = BM * VN / 256, RSTEP = 256 / VN;
+  const int cv = tid % VN, rv0 = tid / VN;
+  const int n = n0 + cv * 4;
+  const long mrow0 = ((long)b * p.Ho + y0) * p.Wo + x0;
+  auto out_row = [&](int row) { return mrow0 + (long)(row / PW) * p.Wo + (row % PW); };
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out0);
+  if (p.mode == CONV_RAW_STATS) {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP;
+      st4<bf16_t>(out + out_row(row) * p.Cout + n, *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]));
+    }
+    if (p.stats != nullptr) {  // from the fp32 accumulators, like every other train-mode epilogue
+      constexpr int NG = 256 / BN;
+      const int col = tid % BN, rg = tid / BN;
+      float s1 = 0.f, s2 = 0.f;
+      for (int row = rg; row < BM; row += NG) {
+        const float v = Cs[row * LDC + col];
+        s1 += v;
+        s2 += v * v;
+      }
+      __syncthreads();
+      float* red = lds;
+      red[(rg * BN + col) * 2 + 0] = s1;
+      red[(rg * BN + col) * 2 + 1] = s2;
+      __syncthreads();
+      if (tid < BN) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          a1 += red[(g * BN + tid) * 2 + 0];
+          a2 += red[(g * BN + tid) * 2 + 1];
+        }
+        p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 0] = a1;
+        p.stats[((long)tile * p.CoutPad + n0 + tid) * 2 + 1] = a2;
+      }
+    }
+  } else {  // CONV_EVAL_FUSED: folded BatchNorm (+ ReLU)
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n), sf = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int row = rv0 + i * RSTEP;
+      float4 v = *reinterpret_cast<const float4*>(&Cs[row * LDC + cv * 4]);
+      v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      st4<bf16_t>(out + out_row(row) * p.Cout + n, v);
+    }
+  }
+}
+
 // plan: one workgroup per 4 x 64 output tile, one statistics row per tile
 void conv_patch_plan(ConvParams& p, int dtype) {
-  if (p.KH == 7) {  // encoder.conv1 form: 8 x 32 tiles, 32 filters per workgroup
-    p.patch = 2;
+  if (p.KH == 7) {  // encoder.conv1 form: 8 x 32 tiles, 32 filters per workgroup (8: the bf16-storage kernel)
+    p.patch = dtype == D3F_BF16 ? 8 : 2;
     p.nz = 1;
     p.splitk = 1;
     p.w_ld = p.Kpad;
@@ -692,10 +863,11 @@ void conv_patch_plan(ConvParams& p, int dtype) {
 }
 
 int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
-  if (p.patch == 2) {
-    D3F_CHECK(p.tiles_m == p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW) && p.tiles_n == p.Cout / ST_BN && p.C0 == 4,
+  if (p.patch == 2 || p.patch == 8) {
+    D3F_CHECK(p.tiles_m == p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW) && p.tiles_n == p.Cout / ST_BN && p.C0 == (p.patch == 8 ? 8 : 4),
               "conv: stem patch params were not planned");
-    hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
+    if (p.patch == 8) hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
     D3F_HIP(hipGetLastError());
     return 0;
   }

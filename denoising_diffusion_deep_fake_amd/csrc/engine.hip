@@ -166,7 +166,7 @@ int UnetEngine::add_unit(const std::string& conv_name, const std::string& bn_nam
 int UnetEngine::plan_unit(Unit& u) {
   ConvParams& f = u.fwd;
   std::memset(&f, 0, sizeof(f));
-  f.B = B; f.Hv = u.Hv; f.Wv = u.Wv; f.C0 = u.C0; f.C1 = u.C1;
+  f.B = B; f.Hv = u.Hv; f.Wv = u.Wv; f.C0 = u.C0; f.C1 = u.C1; f.cin_real = u.CinReal;
   f.H0s = u.Hv >> u.up0; f.W0s = u.Wv >> u.up0; f.shift0 = u.up0; f.zi = 0;
   f.Ho = u.Ho; f.Wo = u.Wo; f.Cout = u.Cout; f.CoutPad = u.CoutPad; f.Kpad = u.Kpad;
   f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;

@@ -112,6 +112,33 @@ def test_stem_weight_gradient_bf16_half_vector(shape):
     assert rel_l2(g6.cpu(), want) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 48, 128)], ids=str)
+def test_stem_forward_bf16_patch_kernel(shape):
+    """encoder.conv1 (7x7 stride 2, 3 -> 64) in bf16 storage through conv_stem_bf16_kernel: the image's 3 channels sit in
+    one 16-byte vector of 8, the kernel stages the first four (the packed weights of channels 3 .. 7 are zero) and
+    contracts four taps per v_mfma_f32_32x32x16_bf16.  Output and statistics against torch on the bf16-rounded operands;
+    finite garbage in the pad channels of the input must not change a bit."""
+    from denoising_diffusion_deep_fake_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, 3, 7, 7, generator=g) / (3 * 49) ** 0.5).bfloat16().float()
+    y_ref = F.conv2d(x, w, None, 2, 3)
+    d = ops.make_desc(B, H, W, 8, 0, 64, 7, 2, 3, False, cin_real=3)
+    wf, _ = ops.pack_weights(d, w.cuda(), dtype=ops.BF16)
+    xh = to_nhwc(x, 8).bfloat16().cuda()
+    y, stats, tiles = ops.conv_forward(d, xh, None, wf, dtype=ops.BF16)
+    assert tiles == B * (H // 2 // 8) * (W // 2 // 32)          # one statistics row per 8 x 32 tile: the patch kernel ran
+    assert rel_l2(to_nchw(y.float().cpu()), y_ref) < 4e-3
+    st = stats.view(tiles, 64, 2).double().sum(0).cpu()
+    assert rel_l2(st[:, 1], (y_ref.double() ** 2).sum((0, 2, 3))) < 1e-5
+    assert (st[:, 0] - y_ref.double().sum((0, 2, 3))).abs().max() < 1e-3 * (1 + st[:, 1].sqrt().max())
+    dirty = xh.clone()
+    dirty[..., 3:] = torch.randn(dirty[..., 3:].shape, generator=g).bfloat16().cuda()
+    y2, stats2, _ = ops.conv_forward(d, dirty, None, wf, dtype=ops.BF16)
+    assert torch.equal(y2, y) and torch.equal(stats2, stats)
+
+
 def test_unet_bf16_training_step():
     import oracle
     from denoising_diffusion_deep_fake_amd import Unet, ops
