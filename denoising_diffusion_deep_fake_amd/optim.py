@@ -121,15 +121,15 @@ class FusedAdam(torch.optim.Optimizer):
             ranges = [(0, flat.numel())]
         else:
             lo, hi, used, gptr, calls, gver = early
+            if calls != m._rt.get("backward_calls", 0):
+                raise RuntimeError("FusedAdam(overlap_tail=True): another backward() ran before step(), but part of this "
+                                   "step's update already ran inside the first one (gradient accumulation needs "
+                                   "overlap_tail=False)")
             if grads._version != gver:
                 raise RuntimeError("FusedAdam(overlap_tail=True): the gradients were modified in place between backward() "
                                    "and step() (gradient clipping, GradScaler.unscale_, a hook that rescales .grad?), but "
                                    "the update of layer3 / layer4 / decoder / head already ran inside backward() with the "
                                    "unmodified values; build the optimiser with overlap_tail=False for such steps")
-            if calls != m._rt.get("backward_calls", 0):
-                raise RuntimeError("FusedAdam(overlap_tail=True): another backward() ran before step(), but part of this "
-                                   "step's update already ran inside the first one (gradient accumulation needs "
-                                   "overlap_tail=False)")
             if used != hyper or gptr != grads.data_ptr():
                 raise RuntimeError("FusedAdam(overlap_tail=True): lr / betas / eps / grad_scale or the gradient buffer "
                                    f"changed between backward() and step() ({used} -> {hyper}); part of this step's "

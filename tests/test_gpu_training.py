@@ -647,6 +647,24 @@ def test_adam_overlap_tail_contract_violations_are_loud():
     opt.param_groups[0]["lr"] *= 0.5
     with pytest.raises(RuntimeError, match="changed between backward"):
         opt.step()
+    # (c) the gradients edited in place between backward and step (gradient clipping / GradScaler.unscale_ would
+    # otherwise reach only the last bucket's 6 % of the parameters) -- detected through the flat buffer's version counter
+    torch.manual_seed(1)
+    lit = LitModule(**hp).cuda().train()
+    (opt,), _ = lit.configure_optimizers()
+    opt.zero_grad(set_to_none=True)
+    lit.training_step({"image": x, "index": None}, 0).backward()
+    assert opt._early is not None
+    torch.nn.utils.clip_grad_norm_(lit.model.parameters(), 1e-3)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        opt.step()
+    # ... and a later optimiser for the same module with the flag off takes the module's hook away from the first one
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    opt2 = FusedAdam(lit.model.parameters(), lr=0.01, module=lit.model, overlap_tail=False)
+    opt2.zero_grad(set_to_none=True)
+    lit.training_step({"image": x, "index": None}, 1).backward()
+    assert opt2._early is None and opt.early_updates == 1
+    opt2.step()
 
 
 def test_graph_step_metrics_rows_are_per_step_values(tmp_path):
