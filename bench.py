@@ -67,6 +67,9 @@ def parse():
                     help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 2 = (head .. "
                          "layer3) | (layer2 .. stem) (default: 1.3 %% machinery tax on one GPU against 3.2 %% for 4), 4 = one "
                          "per engine segment, 1 = one all-reduce at the end")
+    ap.add_argument("--dp-compress", default="none", choices=["none", "bf16"],
+                    help="N > 1: gradient buckets travel as bfloat16 (DataParallel(grad_compress='bf16'): half the bytes on "
+                         "xGMI, bf16 sums like torch DDP's compression hook); default: fp32, exact")
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "180")),
                     help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
                          "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")
@@ -632,7 +635,7 @@ def main():
     (opt,), _ = lit.configure_optimizers()
     lit.attach_optimizers([opt])
     stage["name"] = "parameter broadcast (DataParallel)"
-    DataParallel(lit.model, opt, buckets=args.dp_buckets)
+    DataParallel(lit.model, opt, buckets=args.dp_buckets, grad_compress=None if args.dp_compress == "none" else args.dp_compress)
     if world > 1:
         stage["name"] = "first barrier"
         dist.barrier()
@@ -741,6 +744,7 @@ def main():
                    "adam_overlap_tail_steps": int(opt.early_updates),
                    # N > 1: gradient exchange buckets per backward pass; parameter bits equal on every rank after the run
                    "dp_buckets": args.dp_buckets if world > 1 else None,
+                   "dp_grad_compress": (args.dp_compress if world > 1 else None),
                    "replicas_bit_identical": replicas_identical,
                    # what the collective layer saw (None at N=1: no process group, no exchange step)
                    "backend": dist.get_backend() if world > 1 else None,

@@ -151,6 +151,20 @@ def _rccl_worker(rank, port, ret):
     torch.cuda.synchronize()
     ret["equal"] = bool(torch.equal(plain, hooked))
     ret["finite"] = bool(torch.isfinite(net.flat_params).all())
+    # the opt-in bf16 gradient buckets through the SAME path (staging copy on the engine's side stream, RCCL all-reduce of
+    # the bf16 buffer, write-back in wait()): with one rank the result is the fp32 gradient rounded to bf16 once -- with
+    # 2 and with 4 exchange buckets
+    for buckets in (2, 4):
+        redc = BucketAllReducer(force=True, compress="bf16")
+        net.set_grad_sync(redc, buckets)
+        for p in net.parameters():
+            p.grad = None
+        pred = net(x)
+        _, g = ops.mse_ssim_loss(pred.detach(), x)
+        pred.backward(g)
+        redc.wait()
+        torch.cuda.synchronize()
+        ret[f"bf16_{buckets}"] = bool(torch.equal(net.flat_grads, plain.bfloat16().float()))
     dist.destroy_process_group()
 
 
@@ -162,6 +176,7 @@ def test_rccl_backend_single_rank():
     ret = mgr.dict()
     _spawn_with_deadline(_rccl_worker, (_free_port(), ret), 1, seconds=200)
     assert ret.get("equal") is True and ret.get("finite") is True, dict(ret)
+    assert ret.get("bf16_2") is True and ret.get("bf16_4") is True, dict(ret)
 
 
 def test_bench_contract_two_ranks(tmp_path):
