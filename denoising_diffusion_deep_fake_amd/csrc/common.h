@@ -199,6 +199,7 @@ struct ConvParams {
   int sum2;            // CONV_DGRAD request (set before the plan): store the 2x2 block sums of the gradient at HALF resolution
                        // (the gradient w.r.t. a source that was read through the nearest x2 up-sampling); kept only when
                        // a patch kernel takes the launch -- the plan clears it otherwise and the caller reduces itself
+  // (9 / 10 / 11: conv_pres_kernel for 64 / 128 / 256 channels, conv_pres.hip)
   int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
 };
 
@@ -232,6 +233,10 @@ int conv_winograd_stat_rows(const ConvParams& p);           // one statistics ro
 size_t conv_winograd_filter_floats(const ConvParams& p);    // U[16][Cin / 16][Cout][16]
 int conv_winograd_pack_launch(const float* w /*[Cout][Cin][3][3]*/, float* u, int Cout, int Cin, hipStream_t stream);
 int conv_winograd_launch(const ConvParams& p /*w = U*/, hipStream_t stream);
+// conv_pres.hip: patch-resident implicit GEMM of the wide 3x3 stride-1 layers in bf16 storage (chosen inside conv_igemm_plan)
+bool conv_pres_applies(const ConvParams& p, int dtype);
+void conv_pres_plan(ConvParams& p);
+int conv_pres_launch(const ConvParams& p, hipStream_t stream);
 bool conv_patch_applies(const ConvParams& p, int dtype);
 bool conv_stem_applies(const ConvParams& p, int dtype);  // encoder.conv1 (7x7 stride 2, 4 staged channels)
 bool conv_stem_bf16_applies(const ConvParams& p, int dtype);  // ... in bf16 storage (one 16-byte vector per pixel)

@@ -1524,6 +1524,10 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
     conv_patch_plan(p, dtype);
     return 0;
   }
+  if (conv_pres_applies(p, dtype)) {  // wide 3x3 stride-1 layers, bf16 storage: patch-resident form (conv_pres.hip)
+    conv_pres_plan(p);
+    return 0;
+  }
   p.sum2 = 0;  // (a request the implicit GEMM does not serve: full-resolution output, the caller sums the 2x2 blocks)
   const ConvTile t = pick_tile(p, dtype == D3F_F32X3, dtype == D3F_BF16);
   p.tiles_m = cdiv(p.M, t.BM);
@@ -1612,7 +1616,8 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   const int prof_cls = q.mode == CONV_DGRAD ? PROF_CONV_DGRAD : PROF_CONV_FWD;
   const bool prof = prof_enabled(prof_cls);
   if (prof) prof_begin(prof_cls, q.flops, stream);
-  int rc = q.patch            ? conv_patch_launch(q, stream)
+  int rc = q.patch >= 9       ? conv_pres_launch(q, stream)
+           : q.patch          ? conv_patch_launch(q, stream)
            : dtype == D3F_F32X3 ? launch_t<float, true>(q, smallc, stream)
            : dtype == D3F_F32 ? launch_t<float, false>(q, smallc, stream)
                               : launch_t<bf16_t, false>(q, smallc, stream);
