@@ -560,8 +560,18 @@ def pmc_from_file(name, key, args):
     """PMC counters cannot be read from inside this process.  Figures collected by the builder with rocprofv3 (separate
     --pmc passes, gfx950 corrections; profiles/tools/collect_*.sh) are attached WITH their provenance, and only for the
     configuration they were collected on -- they are not measurements of this run."""
-    path = os.path.join(ROOT, "profiles", name)
-    if not (os.path.exists(path) and args.dtype == "f32" and args.size == 256 and args.batch == 16):
+    # the newest round's file first (profiles/rNN_<name>); bf16 / 128 / 448 have their own files
+    tag = {("f32", 256, 16): "", ("bf16", 256, 16): "bf16_", ("f32", 128, 16): "128_", ("f32", 448, 14): "448_"}.get(
+        (args.dtype, args.size, args.batch))
+    if tag is None:
+        return None, None
+    path = None
+    for rnd in ("r05", "r04"):
+        cand = os.path.join(ROOT, "profiles", f"{rnd}_{tag}{name}")
+        if os.path.exists(cand):
+            path, name = cand, f"{rnd}_{tag}{name}"
+            break
+    if path is None:
         return None, None
     try:
         d = json.load(open(path))
@@ -774,8 +784,8 @@ def main():
         # ROOFLINE FIGURE: every launch of the dominant kernel (forward AND data gradient) of the sampled steps
         t_all, f_all, n_all = ms[0] + ms[1], fl[0] + fl[1], n[0] + n[1]
         ach = f_all / t_all / 1e9
-        traffic, tsrc = pmc_from_file("r04_traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
-        busy, bsrc = pmc_from_file("r04_mfma_util.json", lambda d: next(
+        traffic, tsrc = pmc_from_file("traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args)
+        busy, bsrc = pmc_from_file("mfma_util.json", lambda d: next(
             (k["mfma_pipe_busy"] for k in d.get("kernels", []) if k["kernel"] == "conv_igemm"), None), args)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
 
   // ---- weight tiles: iteration `it` = k-tiles it * KW .. it * KW + KW - 1 = k [it * KW * 64, +KW * 64) of every row
-  uint4 wv[NBV];
+  // Two register sets: the tile of iteration it + 2 is requested while iteration it computes, so a weight tile has two
+  // iterations to arrive from L2 (with one set the loop waited for the L2 latency every iteration: 4-8 MFMAs cover ~150
+  // cycles of it).  The loop is fully unrolled, so the set index is a compile-time constant.
+  uint4 wv[2][NBV];
   unsigned woff[NBV];  // byte offset of this thread's vectors at iteration 0 (or BUF_OOB)
   int wdst[NBV];
 #pragma unroll
@@ -80,18 +83,19 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
     woff[j] = (n0 + row) < p.CoutPad ? (unsigned)((n0 + row) * p.w_ld + g * 64 + vec * 8) * 2u : BUF_OOB;
     wdst[j] = (g * BN + row) * BROW + vec * 4;
   }
-  auto load_w = [&](int it) {
+  auto load_w = [&](int it, int set) {
 #pragma unroll
-    for (int j = 0; j < NBV; ++j) wv[j] = buf_load16s(rw, woff[j], (unsigned)(it * KW * 128));
+    for (int j = 0; j < NBV; ++j) wv[set][j] = buf_load16s(rw, woff[j], (unsigned)(it * KW * 128));
   };
-  auto store_w = [&](int stage) {
+  auto store_w = [&](int stage, int set) {
 #pragma unroll
-    for (int j = 0; j < NBV; ++j) *reinterpret_cast<uint4*>(&Bs[stage * G::BST_DW + wdst[j]]) = wv[j];
+    for (int j = 0; j < NBV; ++j) *reinterpret_cast<uint4*>(&Bs[stage * G::BST_DW + wdst[j]]) = wv[set][j];
   };
-  load_w(0);
+  load_w(0, 0);
+  if (NIT > 1) load_w(1, 1);
 
   // ---- the patch: (TR + 2) x (TW + 2) pixels x C channels, zeros outside the image -----------------------------------
-  constexpr int PB = 8;  // vectors in flight per thread and batch
+  constexpr int PB = (NPV + 255) / 256;  // every vector of the patch in flight at once (9 / 13 / 14 per thread)
   for (int base = 0; base < NPV; base += 256 * PB) {
     uint4 pv[PB];
 #pragma unroll
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
       if (id < NPV) *reinterpret_cast<uint4*>(&P[pix * PIXD + cv * 4]) = pv[i];
     }
   }
-  store_w(0);
+  store_w(0, 0);
   __syncthreads();
 
   // ---- k-loop ---------------------------------------------------------------------------------------------------------
@@ -129,10 +133,10 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-#pragma unroll 1
+#pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    if (it + 1 < NIT) load_w(it + 1);
-    const int t = __builtin_amdgcn_readfirstlane(it * KW + wk);  // this wave's k-tile: tap t / CH, chunk t % CH
+    if (it + 2 < NIT) load_w(it + 2, it & 1);  // (set it & 1 was stored to LDS at the end of iteration it - 1)
+    const int t = KW == 1 ? it : __builtin_amdgcn_readfirstlane(it * KW + wk);  // this wave's k-tile: tap t / CH, chunk t % CH
     const int tap = t / CH, ch = t - tap * CH;
     const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
     const float* Ap = P + (kh * PC + kw) * PIXD + ch * 32;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
                                                          *reinterpret_cast<const bf16x8*>(&bb), acc[i], 0, 0, 0);
       }
     }
-    if (it + 1 < NIT) store_w((it + 1) & 1);  // (that stage was last read in iteration it - 1, behind a barrier)
+    if (it + 1 < NIT) store_w((it + 1) & 1, (it + 1) & 1);  // (that stage was last read in iteration it - 1, behind a barrier)
     __syncthreads();
   }
 
