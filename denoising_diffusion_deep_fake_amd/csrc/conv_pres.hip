@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
 }
 
 // one configuration per channel count, sized for the 256-wide network input (layer1 at 64 x 64, layer2 at 32 x 32, layer3
-// at 16 x 16 with 16 images: 512 workgroups each); other extents keep the implicit GEMM
+// at 16 x 16, layer4 at 8 x 8 with 16 images: 512 workgroups each); other extents keep the implicit GEMM
 struct PresPick {
   int id, TW, BM, BN;
 };
@@ -322,6 +322,7 @@ static PresPick pres_pick(const ConvParams& p) {
   if (p.C0 == 64 && p.Wo % 64 == 0) return {1, 64, 128, 64};
   if (p.C0 == 128 && p.Wo % 32 == 0) return {2, 32, 128, 32};
   if (p.C0 == 256 && p.Wo % 16 == 0) return {3, 16, 64, 32};
+  if (p.C0 == 512 && p.Wo % 8 == 0) return {4, 8, 32, 32};
   return {0, 0, 0, 0};
 }
 
@@ -342,7 +343,7 @@ bool conv_pres_applies(const ConvParams& p, int dtype) {
 
 void conv_pres_plan(ConvParams& p) {
   const PresPick k = pres_pick(p);
-  p.patch = 8 + k.id;  // 9 / 10 / 11
+  p.patch = 8 + k.id;  // 9 / 10 / 11 / 12
   p.nz = 1;
   p.splitk = 1;
   p.w_ld = p.Kpad;
@@ -358,7 +359,8 @@ int conv_pres_launch(const ConvParams& p, hipStream_t stream) {
   const dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n), block(256);
   if (k.id == 1) hipLaunchKernelGGL((conv_pres_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, p);
   else if (k.id == 2) hipLaunchKernelGGL((conv_pres_kernel<128, 32, 4, 1, 1, 1>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1>), grid, block, 0, stream, p);
+  else if (k.id == 3) hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 1, 1, 4, 1>), grid, block, 0, stream, p);  // (99 KB of LDS: one workgroup per CU)
   D3F_HIP(hipGetLastError());
   return 0;
 }
