@@ -322,7 +322,7 @@ static PresPick pres_pick(const ConvParams& p) {
   if (p.C0 == 64 && p.Wo % 64 == 0) return {1, 64, 128, 64};
   if (p.C0 == 128 && p.Wo % 32 == 0) return {2, 32, 128, 32};
   if (p.C0 == 256 && p.Wo % 16 == 0) return {3, 16, 64, 32};
-  if (p.C0 == 512 && p.Wo % 8 == 0) return {4, 8, 32, 32};
+  if (p.C0 == 512 && p.Wo % 8 == 0) return {4, 8, 64, 32};  // a whole 8 x 8 image per workgroup: every weight tile serves 64 pixels
   return {0, 0, 0, 0};
 }
 
@@ -338,7 +338,9 @@ bool conv_pres_applies(const ConvParams& p, int dtype) {
   const PresPick k = pres_pick(p);
   if (!k.id || (p.Cout % k.BN) != 0 || (p.Ho % (k.BM / k.TW)) != 0) return false;
   const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN);
-  return wgs >= 384;  // fewer: the implicit GEMM's split tiles fill the chip better
+  // fewer workgroups: the implicit GEMM's split tiles fill the chip better (the 512-channel form holds 122 KB of LDS, one
+  // workgroup per CU: 256 of them are one full round)
+  return wgs >= (k.id == 4 ? 256 : 384);
 }
 
 void conv_pres_plan(ConvParams& p) {
@@ -360,7 +362,7 @@ int conv_pres_launch(const ConvParams& p, hipStream_t stream) {
   if (k.id == 1) hipLaunchKernelGGL((conv_pres_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, p);
   else if (k.id == 2) hipLaunchKernelGGL((conv_pres_kernel<128, 32, 4, 1, 1, 1>), grid, block, 0, stream, p);
   else if (k.id == 3) hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 1, 1, 4, 1>), grid, block, 0, stream, p);  // (99 KB of LDS: one workgroup per CU)
+  else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 2, 1, 2, 1>), grid, block, 0, stream, p);  // (122 KB of LDS: one workgroup per CU)
   D3F_HIP(hipGetLastError());
   return 0;
 }
