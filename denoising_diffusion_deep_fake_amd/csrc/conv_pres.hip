@@ -14,6 +14,9 @@
 //   wave order: reproducible); a wave's tile is (32 FM) x 32.
 //   LDS: patch [(TR+2)(TW+2)][C/2 + 4] dwords (the +16 bytes per pixel make the fragment reads conflict-free) |
 //        weight stages [2][KW][BN][32 + 4] dwords; the fp32 C tile(s) of the epilogue alias the front.
+//   Tried and dropped (profiles/r05_negative_pres_weights_direct.patch): the B fragments straight from L2 into registers (16
+//   bytes of one filter row per lane, no LDS stages, no barrier in the loop) -- 32 rows x 32 bytes per load instruction is an
+//   uncoalesced gather for the texture path: 9.7 -> 20.7 us (128 ch), 11.4 -> 20.5 (256), 10.5 -> 14.8 (64), step 3.79 -> 4.19 ms.
 //   Epilogues as conv_patch.hip: raw output + statistics row per workgroup (train), folded BatchNorm (+ residual)(+ ReLU)
 //   (eval), data gradient with optional accumulate and the consumer's fused BatchNorm-backward partial sums.
 #include "common.h"
@@ -362,7 +365,7 @@ int conv_pres_launch(const ConvParams& p, hipStream_t stream) {
   if (k.id == 1) hipLaunchKernelGGL((conv_pres_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, p);
   else if (k.id == 2) hipLaunchKernelGGL((conv_pres_kernel<128, 32, 4, 1, 1, 1>), grid, block, 0, stream, p);
   else if (k.id == 3) hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 2, 1, 2, 1>), grid, block, 0, stream, p);  // (122 KB of LDS: one workgroup per CU)
+  else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 1, 1, 4, 2>), grid, block, 0, stream, p);  // (141 KB of LDS: one workgroup per CU)
   D3F_HIP(hipGetLastError());
   return 0;
 }
