@@ -154,6 +154,7 @@ def _rccl_worker(rank, port, ret):
     # the opt-in bf16 gradient buckets through the SAME path (staging copy on the engine's side stream, RCCL all-reduce of
     # the bf16 buffer, write-back in wait()): with one rank the result is the fp32 gradient rounded to bf16 once -- with
     # 2 and with 4 exchange buckets
+    plain = grads(None)  # (the optimiser step above moved the parameters)
     for buckets in (2, 4):
         redc = BucketAllReducer(force=True, compress="bf16")
         net.set_grad_sync(redc, buckets)
