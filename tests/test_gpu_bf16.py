@@ -246,6 +246,58 @@ def test_bf16_every_layer_teacher_forced(shape):
     print(f"bf16 teacher-forced {shape}: worst conv output {worst_y:.2e}, worst activation {worst_a:.2e}")
 
 
+@pytest.mark.timeout(900)
+def test_bf16_eval_every_layer_teacher_forced_at_the_headline_batch():
+    """EVAL mode in bf16 storage at 16 x 256 x 256, layer by layer: the eval forward runs the round-5 bf16 kernels with their
+    FUSED epilogues -- conv_pres_kernel (folded BatchNorm + residual + ReLU on the BasicBlock conv2 layers), the bf16 patch
+    kernels and conv_stem_bf16_kernel -- which no train-mode gate touches.  The float64 oracle (eval mode, the same running
+    statistics) is fed the HIP run's own activation in front of every layer, so every comparison sees one layer's
+    conv + folded BatchNorm (+ residual) + ReLU: one bf16 rounding of the output (train mode rounds y first: 3.7e-3; here
+    2^-9 once).  Gate 5.5e-3 as the train-mode test; a missing residual, ReLU or a wrong coefficient row is O(1).
+    Reference path: d3f/train_deep_fake/lit_module.py:259-270 (eval forward of predict_fake)."""
+    import oracle
+    from oracle.pinned import swap_relus, unit_names
+    from denoising_diffusion_deep_fake_amd import Unet
+    B, H, W = 16, 256, 256
+    torch.manual_seed(13)
+    ref = oracle.Unet("resnet34", None, 3, 3, None)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    ref.eval()
+    net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16")
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().eval()
+    x = oracle.synthetic_face_crops(B, (H, W), seed=23)
+    with torch.no_grad():
+        out_hip = net(x.cuda()).cpu()
+    names = unit_names()
+    chan = {n: dict(ref.named_modules())[n].out_channels for n in names}
+    hip_a = {n: net.export_activation(n + ":a").cpu()[:, :chan[n]] for n in names}
+    del net
+    torch.cuda.empty_cache()
+    ref64 = ref.double()
+    queue = [hip_a[n] for n in names]
+    recorded = []
+    swap_relus(ref64, lambda: _TeacherForcedReLU(queue, recorded))
+    with torch.no_grad():
+        out64 = ref64(x.double())
+    assert not queue and len(recorded) == len(names)
+    worst = ("", 0.0)
+    for n, a64 in zip(names, recorded):
+        e = rel_l2(hip_a[n], a64)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < 5.5e-3, ("a", n, e)
+    # the head sees the HIP run's last activation too: fp32 output of a bf16 conv on bf16 operands
+    e_out = rel_l2(out_hip, out64)
+    print(f"bf16 eval teacher-forced {(B, H, W)}: worst activation {worst[1]:.2e} ({worst[0]}), head output {e_out:.2e}")
+    assert e_out < 5.5e-3, e_out
+
+
 # gates of the teacher-forced BACKWARD test = measured on MI355X x 1.5 (gpurun_out/r05_a, worst tensor per class at
 # 4x64x64 / 16x128x128 / 16x256x256): activation gradients 3.79 / 3.84 / 3.86e-3 (decoder.blocks.4.conv1.0); conv weight
 # gradients 4.56 / 5.27 / 8.92e-3 (encoder.layer1.1.conv1.weight: a sum over 65 536 pixels of products whose dy factor

@@ -229,51 +229,6 @@ def test_eval_fused_epilogue_matches_train_path_apply_at_b64():
         assert ((out_eval - out_train).norm() / out_train.norm()).item() < 2e-5
 
 
-def test_eval_fused_epilogue_bf16_matches_train_path_at_the_headline_batch():
-    """The same identity in bf16 storage at 16 x 256 x 256, where the eval forward runs the round-5 bf16 kernels with their
-    fused epilogues -- conv_pres_kernel (folded BatchNorm + RESIDUAL + ReLU on the BasicBlock conv2 layers), the bf16 patch
-    kernels and conv_stem_bf16_kernel.  The train path rounds y to bf16 and then normalises, the eval path normalises the
-    fp32 accumulator and rounds once, so the two differ by bf16 rounding (2^-9 per layer, amplified by the BatchNorm-heavy
-    net like every rounding); a missing residual, ReLU or a wrong coefficient row is O(1).  Gates = measured x 1.5."""
-    from denoising_diffusion_deep_fake_amd import Unet
-    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
-    torch.manual_seed(0)
-    net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16").cuda().train()
-    x = synthetic_face_crops(16, 256, seed=5, device="cuda")
-    names = ["encoder.conv1", "encoder.layer1.0.conv2", "encoder.layer2.0.conv2", "encoder.layer3.5.conv2",
-             "encoder.layer4.2.conv2", "decoder.blocks.0.conv1.0", "decoder.blocks.2.conv2.0", "decoder.blocks.3.conv2.0",
-             "decoder.blocks.4.conv1.0", "decoder.blocks.4.conv2.0"]
-    bns = [(name, m) for name, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d)]
-    with torch.no_grad():
-        for _, m in bns:
-            m.running_mean.zero_()
-            m.running_var.zero_()
-        out_train = net(x)
-        train_a = {n: net.export_activation(n + ":a") for n in names}
-        for name, m in bns:
-            conv = (name.replace(".bn1", ".conv1").replace(".bn2", ".conv2").replace("downsample.1", "downsample.0")
-                    .replace("conv1.1", "conv1.0").replace("conv2.1", "conv2.0"))
-            b, _, h, w = net.export_activation_shape(conv + ":y")
-            n_el = b * h * w
-            m.running_mean.mul_(10.0)
-            m.running_var.mul_(10.0 * (n_el - 1) / n_el)
-        net.eval()
-        out_eval = net(x)
-        worst = 0.0
-        for n in names:
-            e = net.export_activation(n + ":a")
-            err = ((e - train_a[n]).norm() / train_a[n].norm()).item()
-            worst = max(worst, err)
-            assert err < BF16_EVAL_LAYER_TOL, (n, err)
-        err_out = ((out_eval - out_train).norm() / out_train.norm()).item()
-        print(f"bf16 eval vs train path at 16x256x256: worst activation {worst:.2e}, output {err_out:.2e}")
-        assert err_out < BF16_EVAL_OUT_TOL, err_out
-
-
-BF16_EVAL_LAYER_TOL = 1e-1   # provisional; set to measured x 1.5 once measured
-BF16_EVAL_OUT_TOL = 1e-1
-
-
 @pytest.mark.timeout(600)
 def test_sample50_hipgraph_replay_equals_eager_loop_bitwise():
     """BASELINE.json configs[4] as written: 50 eval-mode forwards of B=64 at 256x256, output fed back, with the denoise
