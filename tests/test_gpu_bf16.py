@@ -253,7 +253,8 @@ def test_bf16_eval_every_layer_teacher_forced_at_the_headline_batch():
     kernels and conv_stem_bf16_kernel -- which no train-mode gate touches.  The float64 oracle (eval mode, the same running
     statistics) is fed the HIP run's own activation in front of every layer, so every comparison sees one layer's
     conv + folded BatchNorm (+ residual) + ReLU: one bf16 rounding of the output (train mode rounds y first: 3.7e-3; here
-    2^-9 once).  Gate 5.5e-3 as the train-mode test; a missing residual, ReLU or a wrong coefficient row is O(1).
+    2^-9 once).  Measured on MI355X: worst activation 2.63e-3 (decoder.blocks.4.conv2.0), head output 1.60e-3; gates = x 1.5
+    (4.0e-3 / 2.4e-3).  A missing residual, ReLU or a wrong coefficient row is O(1).
     Reference path: d3f/train_deep_fake/lit_module.py:259-270 (eval forward of predict_fake)."""
     import oracle
     from oracle.pinned import swap_relus, unit_names
@@ -291,11 +292,11 @@ def test_bf16_eval_every_layer_teacher_forced_at_the_headline_batch():
     for n, a64 in zip(names, recorded):
         e = rel_l2(hip_a[n], a64)
         worst = max(worst, (n, e), key=lambda t: t[1])
-        assert e < 5.5e-3, ("a", n, e)
+        assert e < 4.0e-3, ("a", n, e)
     # the head sees the HIP run's last activation too: fp32 output of a bf16 conv on bf16 operands
     e_out = rel_l2(out_hip, out64)
     print(f"bf16 eval teacher-forced {(B, H, W)}: worst activation {worst[1]:.2e} ({worst[0]}), head output {e_out:.2e}")
-    assert e_out < 5.5e-3, e_out
+    assert e_out < 2.4e-3, e_out
 
 
 # gates of the teacher-forced BACKWARD test = measured on MI355X x 1.5 (gpurun_out/r05_a, worst tensor per class at
