@@ -345,7 +345,10 @@ bool conv_pres_applies(const ConvParams& p, int dtype) {
   const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN);
   // fewer workgroups: the implicit GEMM's split tiles fill the chip better (the 512-channel form holds 122 KB of LDS, one
   // workgroup per CU: 256 of them are one full round)
-  return wgs >= (k.id == 4 ? 256 : 384);
+  // ... and many more (B = 64 eval batches: 2048): every workgroup streams the full weight matrix of its filter group, so the
+  // weight traffic grows with the workgroup count and the implicit GEMM's larger tiles win (50 eval forwards of B = 64 in
+  // bf16: 105.6 ms with the implicit GEMM, 114.5 ms with this kernel)
+  return wgs >= (k.id == 4 ? 256 : 384) && wgs <= 1024;
 }
 
 void conv_pres_plan(ConvParams& p) {
