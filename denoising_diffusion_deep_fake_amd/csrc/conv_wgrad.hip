@@ -534,7 +534,11 @@ int wgrad_plan(WgradParams& p, int dtype) {
   p.tiles_ci = cdiv(p.slab_cin, t);
   const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps;
   const int total_chunks = cdiv(p.Mi, KP);
-  const long target = 928;  // ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %)
+  static const long target_env = getenv("D3F_WGRAD_TARGET") ? atol(getenv("D3F_WGRAD_TARGET")) : 0;  // sweep knob
+  // fp32: ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %).  bf16 storage
+  // (round 5 sweep, profiles/README.md: 232 ... 1856): the launches are latency-bound, not MFMA-bound, and the stream is as
+  // long as the chain in the backward window -- 1152 is 1.2 % faster per step than 928, 640 1.4 % slower, 1856 1.8 % slower
+  const long target = target_env > 0 ? target_env : (dtype == D3F_BF16 ? 1152 : 928);
   long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;
