@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // x3: per operand 3 planes x 2 subtiles x [32 pixels][32 channels] bf16
   constexpr int X3_SUB = KP * 64, X3_PLANE = 2 * X3_SUB, X3_OP = (sizeof(T) == 4 ? 3 : 1) * X3_PLANE;  // bytes
   constexpr int F32_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
-  constexpr int LDS_FLOATS = X3 ? 2 * X3_OP / 4 : F32_FLOATS;
+  // bf16 storage: UB chunks of 32 pixels are staged per barrier pair (the matrix work of a chunk is two MFMAs -- with one
+  // chunk per pair the loop was two barriers and a global-load latency per 2 MFMAs)
+#ifndef D3F_WGRAD_UB  // (A/B builds: -DD3F_WGRAD_UB=1 is the loop as before round 5)
+#define D3F_WGRAD_UB 2  // (same-box sweep: 1: 3.817, 2: 3.746, 4: 3.745, 8: 3.97 ms per bf16 step; 2 holds 16 KB of LDS, 4 holds 32)
+#endif
+  constexpr int UB = (X3 && sizeof(T) == 2) ? D3F_WGRAD_UB : 1;
+  constexpr int LDS_FLOATS = X3 ? UB * 2 * X3_OP / 4 : F32_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* Ys = lds;
   float* Xs = lds + KP * LY;
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int j = 0; j < NVX; ++j) xcol[j] = lcol + j * TPR < VX && ci0 + (lcol + j * TPR) * VE < Cin;
   uint4 ry[NVY], rx[NVX];
-  auto load_chunk = [&](int ch) {
-    const bool rowok = lrow < p.Mi - ch * KP;  // the last chunk may be partial
+  auto load_chunk_to = [&](int ch, uint4 (&ry)[NVY], uint4 (&rx)[NVX], bool live) {
+    const bool rowok = live && lrow < p.Mi - ch * KP;  // the last chunk may be partial
     const int b = xb, oy = xoy, ox = xox;
     {
       int nx = ox + p.step_col;
@@ -225,8 +231,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int j = 0; j < NVX; ++j) rx[j] = buf_load16s(rx1, xcol[j] ? ox_off : BUF_OOB, j * VSTEP);
     }
   };
+  auto load_chunk = [&](int ch) { load_chunk_to(ch, ry, rx, true); };
 
-  if (chunk_begin < chunk_end) load_chunk(chunk_begin);
+  if (UB == 1 && chunk_begin < chunk_end) load_chunk(chunk_begin);
   const int fr = lane & 31, fh = lane >> 5;
   if constexpr (X3) {
     typedef short v4s __attribute__((ext_vector_type(4)));
@@ -247,6 +254,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             (__attribute__((address_space(3))) v4s*)(base + pl * X3_PLANE + s * 16 * 64 + h * 4 * 64));
       return f.u;
     };
+    if constexpr (UB > 1) {
+      // bf16 storage: groups of UB chunks; chunks past this slab's range load zeros (load_chunk_to(.., live = false))
+      constexpr int SLOT = 2 * X3_OP;  // bytes per staged chunk (dY | X)
+      uint4 qy[UB][NVY], qx[UB][NVX];
+      auto load_group = [&](int ch0) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) load_chunk_to(ch0 + u, qy[u], qx[u], ch0 + u < chunk_end);
+      };
+      if (chunk_begin < chunk_end) load_group(chunk_begin);
+      for (int ch = chunk_begin; ch < chunk_end; ch += UB) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+#pragma unroll
+          for (int i = 0; i < NVY; ++i)
+            if (lcol + i * TPR < VY) *reinterpret_cast<uint4*>(lb + u * SLOT + lrow * 64 + woff(lcol + i * TPR)) = qy[u][i];
+#pragma unroll
+          for (int i = 0; i < NVX; ++i)
+            if (lcol + i * TPR < VX) *reinterpret_cast<uint4*>(lb + u * SLOT + X3_OP + lrow * 64 + woff(lcol + i * TPR)) = qx[u][i];
+        }
+        __syncthreads();
+        if (ch + UB < chunk_end) load_group(ch + UB);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int s = 0; s < KP / 16; ++s) {
+            const uint4 a = frag(ya + u * SLOT, 0, s), b = frag(xa + u * SLOT, 0, s);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                                *reinterpret_cast<const bf16x8*>(&b), acc[0][0], 0, 0, 0);
+          }
+        __syncthreads();
+      }
+    } else
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
 #pragma unroll
       for (int i = 0; i < NVY; ++i) {
