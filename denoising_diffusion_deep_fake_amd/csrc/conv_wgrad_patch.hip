@@ -370,9 +370,152 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradPa
 //              channels (the tap-parallel kernel took 725 us for this
 //              layer -- 49 taps x 2 filter tiles re-reading the 128x128 dY 49 times -- and sat at the very end of the
 //              weight-gradient stream: profiles/r03_bf16_step_timeline.txt)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 storage, native bf16 matrix cores (round 5).  The kernels above widen bf16 operands to fp32 in LDS and run the fp32
+// MFMA: in bf16 storage the narrow layers' weight gradients were ~0.5 ms of a weight-gradient stream that is as long as
+// the dependent chain in the backward window (profiles/README.md, round 5).  Here both operands stay bf16: the staged
+// images are [pixel][32 channels] rows of 64 bytes (16-channel sources fill the first half of a row, the rest is zero),
+// and the MFMA operands -- 8 consecutive PIXELS of one channel per lane, k = pixel -- are gathered by the transposing LDS
+// read ds_read_b64_tr_b16 exactly as in conv_wgrad_kernel's bf16 loop (two reads per 32 x 16 fragment); a tap is a
+// constant byte offset (kh * PW + kw) * 64 on the patch.  One v_mfma_f32_32x32x16_bf16 per (tile row, tap): 16 pixels x
+// 32 output channels x 32 input channels.  Every 3x3 / stride-1 layer with <= 32 filters and 16 or 32 k input channels
+// runs this ONE shape (narrower sources / filters are zero-padded in LDS; an up-sampled source is gathered at (y >> 1,
+// x >> 1) while staging, so the class-form kernels are not needed: the 9 taps are 9 cheap MFMAs).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PB_TW = 16;
+__global__ __launch_bounds__(256) void conv_wgrad_patch_bf16_kernel(const WgradParams p) {
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  constexpr int TW = PB_TW, KS = 3, PH = PT_TH + 2, PW = TW + 2;
+  constexpr int XB = PH * PW * 64, YB = PT_TH * TW * 64;   // bytes
+  constexpr int RED = 4 * 32 * 32;                           // floats: the four waves' accumulators of one tap
+  constexpr int LDS_B = (XB + YB > RED * 4) ? XB + YB : RED * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char ldsb[LDS_B];
+  unsigned char* Xs = ldsb;
+  unsigned char* Ys = ldsb + XB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cin = p.slab_cin;
+  const int ci_slices = (Cin + 31) / 32;
+  const int slice = blockIdx.y;
+  const int cil0 = (slice % ci_slices) * 32;             // launch-local first input channel of this slice
+  const int ci0 = p.ci_base + cil0, co0 = (slice / ci_slices) * 32;
+  const bool from0 = ci0 < p.C0;
+  const int Cs = from0 ? p.C0 : p.C1;
+  const int sh = from0 ? p.shift0 : 0;
+  const int Hs = from0 ? p.H0s : p.Hv;
+  const int Ws = from0 ? p.W0s : p.Wv;
+  const int cl0 = from0 ? ci0 : ci0 - p.C0;
+  const int xreal = min(32, Cs - cl0), yreal = min(32, p.Cout - co0);   // real channels of this slice (multiples of 8)
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dy_bytes);
+  const __amdgpu_buffer_rsrc_t rx = from0 ? make_rsrc(p.src0, p.src0_bytes) : make_rsrc(p.src1, p.src1_bytes);
+
+  f32x16 acc[KS * KS];
+#pragma unroll
+  for (int j = 0; j < KS * KS; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + PT_TH - 1) / PT_TH;
+  const int ntiles = p.B * tiles_y * tiles_x;
+  constexpr int NVX = (PH * PW * 4 + 255) / 256, NVY = (PT_TH * TW * 4 + 255) / 256;  // 16-byte vectors per thread
+  uint4 rxv[NVX], ryv[NVY];
+  auto issue_loads = [&](int t) {
+    const int b = t / (tiles_y * tiles_x);
+    const int tr = t - b * tiles_y * tiles_x;
+    const int oy0 = (tr / tiles_x) * PT_TH, ox0 = (tr % tiles_x) * TW;
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v >> 2, cv = v & 3;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = oy0 - p.pad + py, ix = ox0 - p.pad + px;
+      const bool ok = v < PH * PW * 4 && cv * 8 < xreal && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+      const int gp = (b * Hs + (iy >> sh)) * Ws + (ix >> sh);
+      rxv[i] = buf_load16(rx, ok ? (unsigned)(gp * Cs + cl0 + cv * 8) * 2u : BUF_OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      const int pix = v >> 2, cv = v & 3;
+      const int y = pix / TW, x = pix - y * TW;
+      const int oy = oy0 + y, ox = ox0 + x;
+      const bool ok = v < PT_TH * TW * 4 && cv * 8 < yreal && oy < p.Ho && ox < p.Wo;
+      ryv[i] = buf_load16(rdy, ok ? (unsigned)(((b * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + cv * 8) * 2u : BUF_OOB);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+      const int v = tid + i * 256;
+      if (v < PH * PW * 4) *reinterpret_cast<uint4*>(Xs + v * 16) = rxv[i];   // [pixel][4 vectors]: 64-byte rows
+    }
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+      const int v = tid + i * 256;
+      if (v < PT_TH * TW * 4) *reinterpret_cast<uint4*>(Ys + v * 16) = ryv[i];
+    }
+  };
+  // transposing fragment gather (conv_wgrad.hip): the 16-lane group g reads 4 pixel rows x 16 channels, lane 4 q + pq
+  // supplies row q, channels 4 pq ..; two reads = 8 consecutive pixels of the lane's channel
+  const int lg = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int rd_lane = ((lg >> 1) * 8 + q) * 64 + ((lg & 1) * 16 + 4 * pq) * 2;
+  auto frag = [&](const unsigned char* base) {
+    union { uint4 u; v4s h[2]; } f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      f.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(base + rd_lane + h * 4 * 64));
+    return f.u;
+  };
+
+  if ((int)blockIdx.x < ntiles) issue_loads(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) issue_loads(t + gridDim.x);
+#pragma unroll
+    for (int yy = 0; yy < PT_TH / 4; ++yy) {
+      const int y = wave * (PT_TH / 4) + yy;
+      const uint4 a = frag(Ys + (y * TW) * 64);
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        const int kh = tap / KS, kw = tap - kh * KS;
+        const uint4 b = frag(Xs + ((y + kh) * PW + kw) * 64);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                           *reinterpret_cast<const bf16x8*>(&b), acc[tap], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- sum the four waves' partial accumulators, one tap at a time; D[co][ci]: ci = lane & 31, co = (r&3) + 8 (r>>2) + 4 (lane>>5)
+  const int taps = KS * KS;
+  float* __restrict__ slab = p.partial + (long)blockIdx.x * p.Cout * taps * Cin;
+  float* red = reinterpret_cast<float*>(ldsb);
+  const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < KS * KS; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lc] = acc[j][r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+      const int co = co0 + (e >> 5), cil = e & 31;
+      if (co < p.Cout && cil < xreal) slab[((long)co * taps + j) * Cin + cil0 + cil] = sum;
+    }
+  }
+}
+
 int wgrad_patch_variant(const WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   if (p.KH != p.KW) return 0;
+#ifndef D3F_NO_WGRAD_PATCH_BF16  // (A/B builds: -DD3F_NO_WGRAD_PATCH_BF16 keeps the widened-to-fp32 kernels)
+  // bf16 storage: every narrow 3x3 stride-1 layer on the native bf16 kernel (7), whole layers only (no class form)
+  if (dtype == D3F_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Cout <= 32 && (cin == 16 || (cin % 32 == 0 && cin <= 128)) &&
+      (p.C1 == 0 || p.C0 % 32 == 0) && (p.C0 % 8) == 0 && (p.C1 % 8) == 0 && (p.Cout % 8) == 0)
+    return 7;
+#endif
   if (p.KH == 3 && p.stride == 1 && p.pad == 1) {
     if (p.Cout <= 16 && cin % 32 == 0 && cin <= 64 && (p.C1 == 0 || p.C0 % 32 == 0)) return 1;
     if (p.Cout <= 16 && cin == 16) return 2;
@@ -389,9 +532,9 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
 
 void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   const int cin = p.part == WG_WHOLE ? p.C0 + p.C1 : p.part == WG_CLASS ? p.C0 : p.C1;  // channels of this launch
-  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : variant == 3 ? 32 : (variant == 5 || variant == 6) ? 8 : 4;
-  const int co_t = (variant == 3 || variant == 4 || variant == 5 || variant == 6) ? 32 : 16;
-  const int slices = (cin / ci_t) * cdiv(p.Cout, co_t) * (p.part == WG_CLASS ? 2 : 1);  // class form: x 2 row parities
+  const int ci_t = variant == 1 ? 32 : variant == 2 ? 16 : (variant == 3 || variant == 7) ? 32 : (variant == 5 || variant == 6) ? 8 : 4;
+  const int co_t = (variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 7) ? 32 : 16;
+  const int slices = cdiv(cin, ci_t) * cdiv(p.Cout, co_t) * (p.part == WG_CLASS ? 2 : 1);  // class form: x 2 row parities
   const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
   int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
   if (g > tiles) g = tiles;
@@ -429,7 +572,10 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
     D3F_HIP(hipGetLastError());
     return 0;
   }
-  if (variant == 4) {
+  if (variant == 7) {
+    D3F_CHECK(dtype == D3F_BF16 && p.part == WG_WHOLE, "wgrad patch: variant 7 is the native bf16 kernel of whole layers");
+    hipLaunchKernelGGL(conv_wgrad_patch_bf16_kernel, grid, block, 0, stream, p);
+  } else if (variant == 4) {
     D3F_CHECK(dtype == D3F_F32, "wgrad patch: stem variant 4 is the f32 one");
     hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (variant == 5) {
