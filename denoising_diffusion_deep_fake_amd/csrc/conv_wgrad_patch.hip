@@ -14,6 +14,8 @@
 // conv_wgrad.hip, reduced by the same fixed-order wgrad_reduce_kernel (bitwise reproducible).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace d3f {
 
 constexpr int PT_TH = 8;  // tile rows: 2 per wave
@@ -536,7 +538,11 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   const int co_t = (variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 7) ? 32 : 16;
   const int slices = cdiv(cin, ci_t) * cdiv(p.Cout, co_t) * (p.part == WG_CLASS ? 2 : 1);  // class form: x 2 row parities
   const int tiles = p.B * cdiv(p.Ho, PT_TH) * cdiv(p.Wo, 16);
-  int g = (256 * 3) / slices;  // ~3 workgroups per CU in total
+  // ~3 workgroups per CU in total; the native bf16 kernel (7): ONE per CU -- its tiles are 18 MFMAs per wave, so fewer,
+  // longer-lived workgroups amortise the nine-tap epilogue and write a third of the slabs (sweep 128 / 192 / 256 / 320 / 384 /
+  // 512 / 768 / 1024 workgroups: 3.64 / 3.55 / 3.46 / 3.53 / 3.48 / 3.49-3.54 / 3.52 / 3.55 ms per bf16 step)
+  static const int g7 = getenv("D3F_WGRAD_PATCH7_WGS") ? atoi(getenv("D3F_WGRAD_PATCH7_WGS")) : 256;  // sweep knob
+  int g = (variant == 7 ? g7 : 256 * 3) / slices;
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   *gx = g;
