@@ -542,7 +542,10 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   // longer-lived workgroups amortise the nine-tap epilogue and write a third of the slabs (sweep 128 / 192 / 256 / 320 / 384 /
   // 512 / 768 / 1024 workgroups: 3.64 / 3.55 / 3.46 / 3.53 / 3.48 / 3.49-3.54 / 3.52 / 3.55 ms per bf16 step)
   static const int g7 = getenv("D3F_WGRAD_PATCH7_WGS") ? atoi(getenv("D3F_WGRAD_PATCH7_WGS")) : 256;  // sweep knob
-  int g = (variant == 7 ? g7 : 256 * 3) / slices;
+  // the fp32-MFMA kernels: 2 per CU (round 5 sweep 384 / 448 / 512 / 576 / 640 / 768 / 1024 workgroups: 7.85 / 7.81 / 7.80 /
+  // 7.94 / 7.91 / 7.875 / 7.91 ms per fp32 step; rounds 1-4 ran 768)
+  static const int gall = getenv("D3F_WGRAD_PATCH_WGS") ? atoi(getenv("D3F_WGRAD_PATCH_WGS")) : 512;  // sweep knob
+  int g = (variant == 7 ? g7 : gall) / slices;
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   *gx = g;
