@@ -514,7 +514,13 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
   if (p.KH != p.KW) return 0;
 #ifndef D3F_NO_WGRAD_PATCH_BF16  // (A/B builds: -DD3F_NO_WGRAD_PATCH_BF16 keeps the widened-to-fp32 kernels)
   // bf16 storage: every narrow 3x3 stride-1 layer on the native bf16 kernel (7), whole layers only (no class form)
-  if (dtype == D3F_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Cout <= 32 && (cin == 16 || (cin % 32 == 0 && cin <= 128)) &&
+  // ... up to 128 filters and 384 input channels (layer1, layer2, decoder blocks 1-4): a workgroup owns one (32 filters x 32
+  // channels) pair, so dY / X are read Cin/32 / Cout/32 times instead of the tap-parallel kernel's 9; round-5 sweep of the
+  // limits (filters, channels) = (32,128) / (64,128) / (128,128) / (128,384) / (256,768) / (512,768): 3.457 / 3.427 / 3.409 and,
+  // on another box, 3.465 (128,128) / 3.435 / 3.432 / 3.450 ms per bf16 step
+  static const int maxco = getenv("D3F_WGRAD_PATCH7_MAXCO") ? atoi(getenv("D3F_WGRAD_PATCH7_MAXCO")) : 128;  // sweep knob
+  static const int maxci = getenv("D3F_WGRAD_PATCH7_MAXCI") ? atoi(getenv("D3F_WGRAD_PATCH7_MAXCI")) : 384;  // sweep knob
+  if (dtype == D3F_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Cout <= maxco && (cin == 16 || (cin % 32 == 0 && cin <= maxci)) &&
       (p.C1 == 0 || p.C0 % 32 == 0) && (p.C0 % 8) == 0 && (p.C1 % 8) == 0 && (p.Cout % 8) == 0)
     return 7;
 #endif
