@@ -56,6 +56,7 @@ PROTOTYPES = {
     "d3f_u8rgb_normalise": (_i, [_p, _p, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _p]),
     "d3f_unet_predict_u8": (_i, [_p, _p, _p, _p, _p, C.POINTER(_f), C.POINTER(_f), _p, _i, _p]),
     "d3f_unet_num_segments": (_i, [_p]),
+    "d3f_unet_plan_counts": (_i, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "d3f_unet_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "d3f_unet_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "d3f_unet_backward_nojoin": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),

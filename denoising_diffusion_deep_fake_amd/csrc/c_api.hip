@@ -276,6 +276,24 @@ int d3f_unet_predict_u8(d3f_unet_t h, const float* params, float* bnstats, const
 }
 
 int d3f_unet_num_segments(d3f_unet_t h) { return h ? h->e.num_segments : -1; }
+int d3f_unet_plan_counts(d3f_unet_t h, int32_t fwd[16], int32_t dgrad[16], int32_t wgrad[16]) {
+  D3F_CHECK(h && fwd && dgrad && wgrad, "unet_plan_counts: null argument");
+  for (int i = 0; i < 16; ++i) fwd[i] = dgrad[i] = wgrad[i] = 0;
+  auto slot = [](int id) { return id < 0 ? 0 : id > 14 ? 14 : id; };
+  for (const Unit& u : h->e.units) {
+    ++fwd[u.wino ? 15 : slot(u.fwd.patch)];
+    if (u.need_dgrad) {
+      if (u.upfold) {
+        ++dgrad[slot(u.dgrad_lo.patch)];
+        if (u.C1 > 0) ++dgrad[slot(u.dgrad.patch)];
+      } else {
+        ++dgrad[slot(u.dgrad.patch)];
+      }
+    }
+    for (int i = 0; i < u.wl.nparts; ++i) ++wgrad[slot(u.wl.part[i].patch)];
+  }
+  return 0;
+}
 int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end) {
   D3F_CHECK(h && segment >= 0 && segment < h->e.num_segments, "segment_range: segment %d", segment);
   *begin = h->e.seg_grad_begin[segment];

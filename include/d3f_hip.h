@@ -112,6 +112,13 @@ int d3f_unet_predict_u8(d3f_unet_t h, const float* params, float* bnstats, const
  * all-reduce bucket k while bucket k+1 computes: run segments [seg_begin, seg_end) in order 0..n;
  * after segment k, grads[begin_k, end_k) (floats) are final. */
 int d3f_unet_num_segments(d3f_unet_t h);
+/* Which kernel family the plan chose for every launch of a training step (a regression guard: falling back to the
+ * implicit GEMM is silent otherwise).  fwd / dgrad count launches by ConvParams::patch (0 = conv_igemm_kernel, 1 / 3-7 =
+ * conv_patch_kernel forms, 2 / 8 = conv_stem[_bf16]_kernel, 9-12 = conv_pres_kernel for 64 / 128 / 256 / 512 channels;
+ * slot 15 of fwd = conv_winograd_kernel), wgrad by WgradParams::patch (0 = tap-parallel conv_wgrad_kernel, 1-6 = the
+ * fp32-MFMA patch kernels incl. the stem's, 7 = conv_wgrad_patch_bf16_kernel).  Replaces nothing in the reference: the
+ * conv2d dispatches of smp.Unet under d3f/train_denoiser/lit_module.py:117 choose their kernels inside ATen. */
+int d3f_unet_plan_counts(d3f_unet_t h, int32_t fwd[16], int32_t dgrad[16], int32_t wgrad[16]);
 int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* end);
 int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
                       void* workspace, int seg_begin, int seg_end, void* stream);

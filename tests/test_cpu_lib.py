@@ -118,3 +118,36 @@ def test_library_digest_matches_sources_and_a_stale_library_is_refused(tmp_path)
     env["D3F_LIB"] = str(pkg / "csrc" / "libd3f_hip.so")
     out = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True)
     assert "LOADED" in out.stdout, (out.stdout, out.stderr)
+
+
+def test_plan_counts_at_the_headline_shapes():
+    """d3f_unet_plan_counts: which kernel family the plan chose for every launch of a training step (planning needs no
+    GPU).  A shape or dtype that silently falls back to the implicit GEMM would only show as a slower step; this pins the
+    plans the round-5 numbers were measured on: fp32 16x256x256 (7 Winograd + 3 patch / stem forward launches, 5 patch
+    weight gradients) and bf16 16x256x256 (32 patch-resident forward + 35 data-gradient launches, 6 + 6 patch-kernel
+    launches, the bf16 stem, 22 native-bf16 patch weight gradients); other extents keep the implicit GEMM for the wide
+    layers."""
+    import ctypes as C
+    from denoising_diffusion_deep_fake_amd import _lib
+    L = _lib.lib()
+
+    def plan(dtype, B, S):
+        h = C.c_void_p()
+        assert L.d3f_unet_create(b"resnet34", 3, 3, B, S, S, dtype, C.byref(h)) == 0, L.d3f_last_error()
+        f, d, w = (C.c_int32 * 16)(), (C.c_int32 * 16)(), (C.c_int32 * 16)()
+        assert L.d3f_unet_plan_counts(h, f, d, w) == 0
+        L.d3f_unet_destroy(h)
+        return list(f), list(d), list(w)
+
+    f, d, w = plan(_lib.F32, 16, 256)
+    assert sum(f) == 47 and f[15] == 7 and f[1] == 2 and f[2] == 1 and f[0] == 37       # Winograd x 7, conv_patch x 2, conv_stem
+    assert sum(d) == 50 and d[1] == 2 and d[0] == 48
+    assert sum(w) == 51 and w[0] == 44 and w[1] + w[2] + w[3] + w[4] == 7 and w[7] == 0  # (class + skip passes count twice)
+    f, d, w = plan(_lib.BF16, 16, 256)
+    assert f[9:13] == [7, 8, 12, 5] and f[8] == 1 and f[3] == 2 and f[4] == 1 and f[5] == 1 and f[0] == 10 and f[15] == 0
+    assert d[9:13] == [8, 9, 13, 5] and d[3] == 1 and d[4] == 2 and d[6] == 1 and d[7] == 1 and d[0] == 10
+    assert w[7] == 22 and w[6] == 1 and w[0] == 25 and sum(w) == 48
+    # 128-wide input and the authors' 448: the wide layers' extents do not match the patch-resident forms -> implicit GEMM
+    for B, S in ((16, 128), (2, 448)):
+        f, d, w = plan(_lib.BF16, B, S)
+        assert sum(f[9:13]) == 0 and sum(d[9:13]) == 0 and f[8] == 1 and w[7] == 22
