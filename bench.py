@@ -355,6 +355,12 @@ def extra_workload(args):
                "ms_per_frame_fused_hipgraph": round(timed(lambda: net.predict_u8(fin, mean, std, graph=True, out=fout), n), 4),
                "ms_per_frame_fused_hipgraph_pcie_inclusive": round(timed(pcie, n), 4)}
         res["frames_per_sec"] = round(1e3 / min(res["ms_per_frame_fused_eager"], res["ms_per_frame_fused_hipgraph"]), 1)
+        best = min(res["ms_per_frame_fused_eager"], res["ms_per_frame_fused_hipgraph"])
+        tf = net.conv_flops(1, size, size, dev)[0] / (best * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                           "frac": round(tf / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                           "basis": "one eval forward of B = 1 (launch-bound: ~50 dependent launches of a few us each), conv FLOPs "
+                                    "counted as the direct convolution's"}
         print(json.dumps(res), flush=True)
         return
     if args.workload == "deepfake":
