@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--dp-compress", default="none", choices=["none", "bf16"],
                     help="N > 1: gradient buckets travel as bfloat16 (DataParallel(grad_compress='bf16'): half the bytes on "
                          "xGMI, bf16 sums like torch DDP's compression hook); default: fp32, exact")
-    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "180")),
+    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "600")),
                     help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
                          "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")
     ap.add_argument("--dp-selftest", action="store_true",

@@ -23,13 +23,13 @@ def env_world():
 
 
 def init_process_group(backend=None, timeout_s=None):
-    """timeout_s (default D3F_DIST_TIMEOUT or 180): the process group's collective timeout -- a rank that never shows up
+    """timeout_s (default D3F_DIST_TIMEOUT or 600): the process group's collective timeout -- a rank that never shows up
     at the rendezvous or a collective that never completes raises on the others instead of hanging the job."""
     world, rank, local = env_world()
     if world > 1 and not dist.is_initialized():
         import datetime
         if timeout_s is None:
-            timeout_s = float(os.environ.get("D3F_DIST_TIMEOUT", "180"))
+            timeout_s = float(os.environ.get("D3F_DIST_TIMEOUT", "600"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
