@@ -338,8 +338,6 @@ bool conv_pres_applies(const ConvParams& p, int dtype) {
   if (!(mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.shift0 == 0 &&
         p.zi == 0 && p.sum2 == 0 && p.Hv == p.Ho && p.Wv == p.Wo && p.Kpad == 9 * p.C0))
     return false;
-  static const char* only = getenv("D3F_PRES_ONLY");  // debugging knob: "f" forward launches only, "d" data gradients only
-  if (only && ((only[0] == 'f' && p.mode == CONV_DGRAD) || (only[0] == 'd' && p.mode != CONV_DGRAD))) return false;
   const PresPick k = pres_pick(p);
   if (!k.id || (p.Cout % k.BN) != 0 || (p.Ho % (k.BM / k.TW)) != 0) return false;
   const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN);

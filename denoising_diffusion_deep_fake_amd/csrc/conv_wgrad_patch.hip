@@ -518,8 +518,8 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
   // channels) pair, so dY / X are read Cin/32 / Cout/32 times instead of the tap-parallel kernel's 9; round-5 sweep of the
   // limits (filters, channels) = (32,128) / (64,128) / (128,128) / (128,384) / (256,768) / (512,768): 3.457 / 3.427 / 3.409 and,
   // on another box, 3.465 (128,128) / 3.435 / 3.432 / 3.450 ms per bf16 step
-  static const int maxco = getenv("D3F_WGRAD_PATCH7_MAXCO") ? atoi(getenv("D3F_WGRAD_PATCH7_MAXCO")) : 128;  // sweep knob
-  static const int maxci = getenv("D3F_WGRAD_PATCH7_MAXCI") ? atoi(getenv("D3F_WGRAD_PATCH7_MAXCI")) : 384;  // sweep knob
+  constexpr int maxco = 128;
+  constexpr int maxci = 384;
   if (dtype == D3F_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Cout <= maxco && (cin == 16 || (cin % 32 == 0 && cin <= maxci)) &&
       (p.C1 == 0 || p.C0 % 32 == 0) && (p.C0 % 8) == 0 && (p.C1 % 8) == 0 && (p.Cout % 8) == 0)
     return 7;
@@ -547,7 +547,7 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   // ~3 workgroups per CU in total; the native bf16 kernel (7): ONE per CU -- its tiles are 18 MFMAs per wave, so fewer,
   // longer-lived workgroups amortise the nine-tap epilogue and write a third of the slabs (sweep 128 / 192 / 256 / 320 / 384 /
   // 512 / 768 / 1024 workgroups: 3.64 / 3.55 / 3.46 / 3.53 / 3.48 / 3.49-3.54 / 3.52 / 3.55 ms per bf16 step)
-  static const int g7 = getenv("D3F_WGRAD_PATCH7_WGS") ? atoi(getenv("D3F_WGRAD_PATCH7_WGS")) : 256;  // sweep knob
+  constexpr int g7 = 256;
   // the fp32-MFMA kernels: 2 per CU (round 5 sweep 384 / 448 / 512 / 576 / 640 / 768 / 1024 workgroups: 7.85 / 7.81 / 7.80 /
   // 7.94 / 7.91 / 7.875 / 7.91 ms per fp32 step; rounds 1-4 ran 768)
   static const int gall = getenv("D3F_WGRAD_PATCH_WGS") ? atoi(getenv("D3F_WGRAD_PATCH_WGS")) : 512;  // sweep knob
