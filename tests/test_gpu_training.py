@@ -740,3 +740,40 @@ def test_denoise_mode_nets_on_two_streams_equal_the_sequential_loop(tmp_path):
         assert torch.equal(sd_c[k], sd_s[k]), k
     swap = LitModule(**dict(HP_FAKE, mode="swap"))
     assert swap.optimizer_streams(torch.device("cuda", 0)) is None
+
+
+def test_fit_on_an_image_list_uint8_batches_equal_float_batches(tmp_path):
+    """End to end on the reference's dataset format (images.txt + PIL, /root/reference/d3f/dataset/image_dataset.py:19-44):
+    Trainer.fit with `uint8_batches: true` (workers hand over HWC uint8 images, Normalize + ToTensor on the GPU through
+    d3f_u8rgb_normalise, pinned staging) must train EXACTLY like the host transform NormalizeToTensor -- the normalisation is
+    bit-identical, so with the same seeds every logged loss and every parameter is bit-equal; two spawned DataLoader workers
+    in the uint8 run exercise the worker -> pinned buffer -> device path the round-5 throughput numbers were measured on."""
+    import re
+    import numpy as np
+    from PIL import Image
+    from denoising_diffusion_deep_fake_amd.train_denoiser.lit_module import LitModule
+    from denoising_diffusion_deep_fake_amd.trainer import Trainer
+    rng = np.random.default_rng(3)
+    (tmp_path / "images").mkdir()
+    names = []
+    for i in range(12):
+        Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(tmp_path / "images" / f"{i}.png")
+        names.append(f"images/{i}.png")
+    (tmp_path / "images.txt").write_text("\n".join(names) + "\n")
+
+    def run(u8, workers):
+        torch.manual_seed(11)
+        hp = dict(HP_DENOISER, synthetic=False, input_image_list_path=str(tmp_path / "images.txt"), uint8_batches=u8,
+                  num_workers=workers, max_epochs=2, default_root_dir=str(tmp_path / f"run_u8{int(u8)}_{workers}"))
+        lit = LitModule(**hp)
+        torch.manual_seed(12)
+        tr = Trainer(max_epochs=2, log_every_n_steps=1, default_root_dir=tmp_path / f"run_u8{int(u8)}_{workers}",
+                     enable_checkpointing=False, flush_every=100).fit(lit)
+        losses = [float(v) for v in re.findall(r"\bloss=([-+0-9.e]+)", (tr.log_dir / "metrics.csv").read_text())]
+        return losses, lit.model.flat_params.clone()
+
+    l_f32, p_f32 = run(False, 0)
+    l_u8, p_u8 = run(True, 0)
+    assert len(l_f32) == 6 and l_f32 == l_u8 and torch.equal(p_f32, p_u8)
+    l_w, p_w = run(True, 2)   # spawned workers + pinned staging: same batches (the sampler's permutation is seeded), same result
+    assert l_w == l_f32 and torch.equal(p_w, p_f32)
