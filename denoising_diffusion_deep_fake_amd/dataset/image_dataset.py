@@ -69,7 +69,7 @@ class ToUint8Tensor:
     value instead of four.  Opt-in through the hyper-parameter `uint8_batches: true`."""
 
     def __call__(self, image):
-        return {"image": torch.from_numpy(np.ascontiguousarray(image))}
+        return {"image": torch.from_numpy(np.array(image))}  # (a writable copy: PIL's decoded buffer is read-only)
 
 
 class NormalizeToTensor:
