@@ -52,6 +52,9 @@ def parse():
                     help="--workload fit with an on-disk list: `uint8_batches: true` -- workers hand over HWC uint8 images, "
                          "Normalize + ToTensor run on the GPU (bit-identical)")
     ap.add_argument("--fit-pin", default="on", choices=["on", "off"], help="--workload fit: DataLoader(pin_memory=...)")
+    ap.add_argument("--fit-module", default="denoiser", choices=["denoiser", "deepfake"],
+                    help="--workload fit: train_denoiser (one net, bs = --batch) or train_deep_fake's denoise mode (two "
+                         "nets, two image lists behind a CombinedLoader, bs = --batch per domain: BASELINE configs[3])")
     ap.add_argument("--fit-augment", default="on", choices=["on", "off"],
                     help="--workload fit: the random affine warp of training_step (the reference always augments)")
     ap.add_argument("--workload", default="denoiser", choices=["denoiser", "deepfake", "sample50", "predict", "fit"],
@@ -202,6 +205,76 @@ def write_image_list(args):
     return lst
 
 
+def fit_workload_deepfake(args):
+    """END TO END for the paired-domain trainer (BASELINE configs[3]): Trainer.fit over train_deep_fake's LitModule in
+    denoise mode -- two on-disk image lists (or two synthetic sets) behind the CombinedLoader (max_size_cycle), the
+    albumentations-style ShiftScaleRotate(p=0.7) on the GPU, two nets stepped one after the other -- next to the same
+    combined step on resident batches.  Reference: d3f/train_deep_fake/lit_module.py:72-111 (loaders), :142-206 (steps)."""
+    import tempfile
+    from denoising_diffusion_deep_fake_amd.trainer import Callback, Trainer, optimizer_steps
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    total = args.warmup + args.steps
+    hp = dict(mode="denoise", batch_size=args.batch, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=10 ** 6,
+              cosine_scheduler_max_epoch=50, num_workers=args.fit_workers, encoder_name="resnet34",
+              noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3, std_b=[0.5] * 3,
+              image_size=args.size, precision=args.dtype, augment=args.fit_augment == "on",
+              uint8_batches=args.fit_uint8 == "on", pin_memory=args.fit_pin == "on")
+    if args.fit_source == "synthetic":
+        hp.update(synthetic=True, synthetic_length=args.fit_files)
+    else:
+        lst = write_image_list(args)
+        hp.update(synthetic=False, data_path_a=lst, data_path_b=lst)  # (two loaders over the same files: two shuffles)
+    lit = LitModule(**hp)
+
+    class Clock(Callback):
+        def __init__(self):
+            self.t0 = self.t1 = None
+            self.n = 0
+
+        def on_train_batch_end(self, trainer, module):
+            self.n += 1
+            if self.n == args.warmup:
+                torch.cuda.synchronize()
+                self.t0 = time.perf_counter()
+            elif self.n == total:
+                torch.cuda.synchronize()
+                self.t1 = time.perf_counter()
+    clock = Clock()
+    with tempfile.TemporaryDirectory() as tmp:
+        tr = Trainer(max_epochs=10 ** 6, max_steps=2 * total, callbacks=[clock], enable_checkpointing=False,
+                     default_root_dir=tmp, log_every_n_steps=50)   # (global_step counts optimiser steps: 2 per batch)
+        tr.fit(lit)
+    fit_s = (clock.t1 - clock.t0) / args.steps
+    # the same combined step on resident batches
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    opts = tr.optimizers
+    opt_params = [[p for g in o.param_groups for p in g["params"]] for o in opts]
+    batch = {k: {"image": synthetic_face_crops(args.batch, args.size, seed=7 + i, device=dev), "index": None}
+             for i, k in enumerate("ab")}
+    for i in range(5):
+        optimizer_steps(lit, opts, opt_params, batch, i, True, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = min(args.steps, 50)
+    for i in range(n):
+        optimizer_steps(lit, opts, opt_params, batch, i, True, None)
+    torch.cuda.synchronize()
+    res_s = (time.perf_counter() - t0) / n
+    out = {"workload": f"Trainer.fit end to end: d3f train_deep_fake (denoise mode, two nets), {args.size}x{args.size}, "
+                       f"bs={args.batch} per domain, {args.fit_source} dataset x 2 behind the CombinedLoader, "
+                       f"{args.fit_workers} DataLoader workers per loader, augment {args.fit_augment}, uint8 batches "
+                       f"{args.fit_uint8}, pinned {args.fit_pin}",
+           "dtype": args.dtype, "steps": args.steps, "warmup": args.warmup,
+           "images_per_sec_fit": round(2 * args.batch / fit_s, 1), "ms_per_combined_batch_fit": round(1e3 * fit_s, 3),
+           "images_per_sec_resident_same_process": round(2 * args.batch / res_s, 1),
+           "ms_per_combined_batch_resident": round(1e3 * res_s, 3), "fit_over_resident": round(res_s / fit_s, 4),
+           "host_cores": usable_cores()}
+    print(json.dumps(out), flush=True)
+
+
 def fit_workload(args):
     """END TO END: images/s through Trainer.fit -> DataLoader (spawned workers) -> _to_device -> (affine warp) -> noise
     blend -> U-Net step, next to the same step on resident batches (what `python bench.py` times) and to the loader and
@@ -308,7 +381,7 @@ def fit_workload(args):
 def extra_workload(args):
     """secondary workloads of BASELINE.json (not the headline metric): one JSON line each."""
     if args.workload == "fit":
-        return fit_workload(args)
+        return fit_workload_deepfake(args) if args.fit_module == "deepfake" else fit_workload(args)
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
