@@ -30,7 +30,9 @@ static bool pres_off() {
   return off;
 }
 
-template <int C, int TW, int MW, int NW, int KW, int FM> struct PresGeo {
+// S1: ONE weight stage in LDS (two barriers per iteration instead of one; the tiles still arrive two iterations ahead in
+// registers) -- 9-18 KB less LDS per workgroup, for the data gradients, which run next to the weight-gradient stream
+template <int C, int TW, int MW, int NW, int KW, int FM, bool S1 = false> struct PresGeo {
   static_assert(MW * NW * KW == 4, "4 waves");
   static constexpr int BM = 32 * MW * FM, BN = 32 * NW;
   static_assert(BM % TW == 0, "whole tile rows");
@@ -47,15 +49,16 @@ template <int C, int TW, int MW, int NW, int KW, int FM> struct PresGeo {
   static constexpr int BST_DW = KW * BN * BROW;  // one weight stage
   static constexpr int LDC = BN + 4;
   static constexpr int CT_DW = KW * BM * LDC;    // C tile(s)
-  static constexpr int LDS_DW = (PATCH_DW + 2 * BST_DW > CT_DW) ? PATCH_DW + 2 * BST_DW : CT_DW;
+  static constexpr int NST = S1 ? 1 : 2;
+  static constexpr int LDS_DW = (PATCH_DW + NST * BST_DW > CT_DW) ? PATCH_DW + NST * BST_DW : CT_DW;
   static constexpr int NBV = BN * KW * 8 / 256;  // weight vectors per thread and iteration
   static_assert(NBV >= 1 && NBV * 256 == BN * KW * 8, "whole weight vectors per thread");
 };
 
-template <int C, int TW, int MW, int NW, int KW, int FM>
+template <int C, int TW, int MW, int NW, int KW, int FM, bool S1 = false>
 __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
   chain_priority();
-  using G = PresGeo<C, TW, MW, NW, KW, FM>;
+  using G = PresGeo<C, TW, MW, NW, KW, FM, S1>;
   constexpr int BM = G::BM, BN = G::BN, TR = G::TR, PC = G::PC, PIXD = G::PIXD, BROW = G::BROW, CV = G::CV;
   constexpr int CH = G::CH, NIT = G::NIT, NPV = G::NPV, NBV = G::NBV, LDC = G::LDC;
   __shared__ __attribute__((aligned(16))) float lds[G::LDS_DW];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
     const int tap = t / CH, ch = t - tap * CH;
     const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
     const float* Ap = P + (kh * PC + kw) * PIXD + ch * 32;
-    const float* Bp = Bs + (it & 1) * G::BST_DW + bbase;
+    const float* Bp = Bs + (S1 ? 0 : (it & 1)) * G::BST_DW + bbase;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const uint4 bb = *reinterpret_cast<const uint4*>(Bp + s * 8);
@@ -154,7 +157,12 @@ __global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
                                                          *reinterpret_cast<const bf16x8*>(&bb), acc[i], 0, 0, 0);
       }
     }
-    if (it + 1 < NIT) store_w((it + 1) & 1, (it + 1) & 1);  // (that stage was last read in iteration it - 1, behind a barrier)
+    if constexpr (S1) {
+      __syncthreads();  // every wave is done reading the stage
+      if (it + 1 < NIT) store_w(0, (it + 1) & 1);
+    } else {
+      if (it + 1 < NIT) store_w((it + 1) & 1, (it + 1) & 1);  // (that stage was last read in iteration it - 1, behind a barrier)
+    }
     __syncthreads();
   }
 
@@ -365,6 +373,17 @@ int conv_pres_launch(const ConvParams& p, hipStream_t stream) {
   D3F_CHECK(k.id && p.patch == 8 + k.id && p.tiles_m == p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) && p.tiles_n == p.Cout / k.BN,
             "conv: patch-resident params were not planned");
   const dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n), block(256);
+  // data gradients: one weight stage (47 / 60 / 66 / 122 KB instead of 56 / 65 / 75 / 141): in the backward pass the launches
+  // share the CUs with the weight-gradient stream's workgroups, and the LDS they leave free is co-residency
+  // (same box: 3.388 / 3.389 / 3.407 -> 3.373 / 3.370 / 3.377 ms per bf16 step)
+  if (p.mode == CONV_DGRAD) {
+    if (k.id == 1) hipLaunchKernelGGL((conv_pres_kernel<64, 64, 2, 2, 1, 2, true>), grid, block, 0, stream, p);
+    else if (k.id == 2) hipLaunchKernelGGL((conv_pres_kernel<128, 32, 4, 1, 1, 1, true>), grid, block, 0, stream, p);
+    else if (k.id == 3) hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_pres_kernel<512, 8, 1, 1, 4, 2, true>), grid, block, 0, stream, p);
+    D3F_HIP(hipGetLastError());
+    return 0;
+  }
   if (k.id == 1) hipLaunchKernelGGL((conv_pres_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, p);
   else if (k.id == 2) hipLaunchKernelGGL((conv_pres_kernel<128, 32, 4, 1, 1, 1>), grid, block, 0, stream, p);
   else if (k.id == 3) hipLaunchKernelGGL((conv_pres_kernel<256, 16, 2, 1, 2, 1>), grid, block, 0, stream, p);
