@@ -313,8 +313,11 @@ BF16_BWD_TOL_BN = 7.7e-3
 @pytest.mark.parametrize("shape", [(4, 64, 64), (16, 128, 128), (16, 256, 256)],
                          ids=["4x64x64", "config1_16x128x128", "headline_16x256x256"])
 def test_bf16_every_layer_backward_teacher_forced(shape):
-    """The bf16 engine plan's BACKWARD pass tensor by tensor (it differs from the fp32 plan: 64x32 k-split tiles, bf16
-    split-K, half-vector stem weight gradient, bf16 `bn_fused` backward, no Winograd, no fp32 `conv_patch`).  The float64
+    """The bf16 engine plan's BACKWARD pass tensor by tensor (it differs from the fp32 plan: at 16 x 256 x 256 the
+    patch-resident conv_pres_kernel for 35 data gradients, the bf16 patch kernels incl. the 2x2-summed data gradient of
+    decoder block 4 conv1 with its fused BatchNorm partial sums, conv_wgrad_patch_bf16_kernel for 22 weight gradients, the
+    two-chunk bf16 tap-parallel loop; at the smaller shapes 64x32 k-split tiles and bf16 split-K; half-vector stem weight
+    gradient, bf16 `bn_fused` backward, no Winograd -- `d3f_unet_plan_counts`, tests/test_cpu_lib.py).  The float64
     oracle is teacher-forced in BOTH directions (oracle/pinned.py:teacher_forced_backward): the forward sees the HIP run's
     bf16 activation in front of every layer with ReLU / max-pool decisions pinned to it, and the gradient arriving at
     every unit's activation is replaced by the HIP run's exported ":da" after the oracle's own value was recorded.  Every
