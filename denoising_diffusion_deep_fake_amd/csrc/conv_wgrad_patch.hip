@@ -44,7 +44,10 @@ template <> __device__ __forceinline__ void patch_store_f32<bf16_t>(float* dst, 
 }
 
 // T: activation type in memory; bf16 operands are widened to f32 when staged (f32 MFMA, f32 accumulate)
-template <typename T, int MT, int CI_T, int KS, int S, int TW>
+// CR (small-channel layers, CI_T < MT): REAL channels per tap that get an output column.  The stem stages 4 channels of which
+// 3 are the image's; with CR = 3 the 49 taps are 147 columns = 5 column tiles instead of 196 -> 7 (a quarter of the MFMAs
+// computed the gradient of the zero pad channel); the pad channels' slab entries are written as zeros.
+template <typename T, int MT, int CI_T, int KS, int S, int TW, int CR = CI_T>
 __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams p) {
   constexpr int VE = Elem<T>::VE;
   constexpr int CO_T = MT;
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
   static_assert(!HALFV || (CI_T == 4 && VE == 8), "half vectors: 4 of 8 bf16 channels");
   constexpr int PH = (PT_TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int KSTEP = (MT == 32) ? 2 : 4;            // pixels per MFMA
-  constexpr int NCOL = KS * KS * CI_T;                 // (tap, ci) columns
+  static_assert(CR == CI_T || (CR < CI_T && CI_T < MT), "fewer columns than staged channels: small-channel path only");
+  constexpr int NCOL = KS * KS * CR;                   // (tap, ci) columns
   constexpr int NNT = (NCOL + MT - 1) / MT;            // column tiles per wave
   // LDS row strides (floats).  X rows: consecutive pixels (the 2 or 4 lane groups of one MFMA operand)
   // must land on disjoint banks: stride*S == MT (mod 32) for MT = 16; any 16-byte multiple for MT = 32.
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 #pragma unroll
     for (int j = 0; j < NNT; ++j) {
       const int n = j * MT + lc;
-      int tap = n / CI_T;
-      const int c = n - tap * CI_T;
+      int tap = n / CR;
+      const int c = n - tap * CR;
       if (tap >= KS * KS) tap = KS * KS - 1;  // padding columns: any valid address, never stored
       const int kh = tap / KS, kw = tap - kh * KS;
       loff[(CI_T >= MT) ? 0 : j] = (kh * PW + kw) * LXS + c;
@@ -212,11 +216,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
       const float s = (red[e] + red[MT * MT + e]) + (red[2 * MT * MT + e] + red[3 * MT * MT + e]);
       const int co = co0 + e / MT;
       const int n = j * MT + (e % MT);
-      const int tap = n / CI_T, ci = cil0 + (n - tap * CI_T);
+      const int tap = n / CR, ci = cil0 + (n - tap * CR);
       if (co < p.Cout && tap < taps) {
         slab[((long)co * taps + tap) * Cin + ci] = s;
-        if constexpr (HALFV) slab[((long)co * taps + tap) * Cin + ci + CI_T] = 0.f;  // the unstaged padding channels
+        if constexpr (HALFV && CR == CI_T) slab[((long)co * taps + tap) * Cin + ci + CI_T] = 0.f;  // the unstaged padding channels
       }
+    }
+  }
+  if constexpr (CR < CI_T) {  // channels CR .. Cin - 1 of every (filter, tap): no column computes them -> zeros
+    const int npad = Cin - CR;
+    for (int e = tid; e < MT * taps * npad; e += 256) {
+      const int c = CR + e % npad, q = e / npad, tap = q % taps, co = co0 + q / taps;
+      if (co < p.Cout) slab[((long)co * taps + tap) * Cin + c] = 0.f;
     }
   }
 }
@@ -592,13 +603,15 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
     hipLaunchKernelGGL(conv_wgrad_patch_bf16_kernel, grid, block, 0, stream, p);
   } else if (variant == 4) {
     D3F_CHECK(dtype == D3F_F32, "wgrad patch: stem variant 4 is the f32 one");
-    hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
+    if (p.cin_real == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16, 3>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_patch_kernel<float, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (variant == 5) {
     D3F_CHECK(dtype == D3F_BF16, "wgrad patch: stem variant 5 is the bf16 one");
     hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 8, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (variant == 6) {
     D3F_CHECK(dtype == D3F_BF16, "wgrad patch: stem variant 6 is a bf16 one");
-    hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
+    if (p.cin_real == 3) hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 4, 7, 2, 16, 3>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_patch_kernel<bf16_t, 32, 4, 7, 2, 16>), grid, block, 0, stream, p);
   } else if (dtype == D3F_F32) {
     if (int rc = patch_launch_t<float>(p, variant, grid, stream)) return rc;
   } else {
