@@ -61,18 +61,31 @@ def parse():
                     help="denoiser: headline (train_denoiser step); deepfake: paired-domain train_deep_fake "
                          "step (BASELINE config 3, bs 8 per domain); sample50: 50 eval-mode forwards of a "
                          "batch of 64 (BASELINE config 4)")
+    ap.add_argument("--mode", default="denoise", choices=["denoise", "swap"],
+                    help="--workload deepfake: train_deep_fake's `mode` -- denoise (denoise_config.yml, 50 epochs) or swap "
+                         "(swap_config.yml, the reference's 200-epoch phase: EMA update + teacher forward under no_grad + "
+                         "student step per optimizer, d3f/train_deep_fake/lit_module.py:183-206)")
+    ap.add_argument("--pair-fused", default="auto", choices=["auto", "on", "off"],
+                    help="--workload deepfake, denoise mode: the two nets' steps as ONE set of launches (trainer.optimizer_steps "
+                         "takes the fused route when the module offers it); off = Lightning's one-after-the-other loop")
     ap.add_argument("--graph-step", default="off", choices=["on", "off"],
                     help="on: the whole optimiser step replayed from one captured hipGraph (graph_step.py; single GPU).  "
                          "Bit-identical to the eager step, and SLOWER on this ROCm (measured r03: bf16 4.6 -> 10.9 ms, "
                          "128x128 3.8 -> 11.5 ms per step: a replayed graph whose nodes span three captured streams costs "
                          "~30 us per node; captured on one stream it equals the eager single-stream step) -- off by default")
-    ap.add_argument("--dp-buckets", type=int, default=2, choices=[1, 2, 4],
+    ap.add_argument("--dp-buckets", type=int, default=None, choices=[1, 2, 4],
                     help="gradient exchange buckets per backward pass at N > 1 (DataParallel(buckets=...)): 2 = (head .. "
-                         "layer3) | (layer2 .. stem) (default: 1.3 %% machinery tax on one GPU against 3.2 %% for 4), 4 = one "
-                         "per engine segment, 1 = one all-reduce at the end")
-    ap.add_argument("--dp-compress", default="none", choices=["none", "bf16"],
+                         "layer3) | (layer2 .. stem) (1.3 %% machinery tax on one GPU against 3.2 %% for 4), 4 = one "
+                         "per engine segment, 1 = one all-reduce at the end.  Default: MEASURED -- the ranks time "
+                         "--dp-autotune-steps steps of 2 and of 4 buckets behind the warm-up, agree on the faster one "
+                         "(max over ranks) and run the timed region with it (config.dp_autotune holds the table)")
+    ap.add_argument("--dp-compress", default=None, choices=["none", "bf16"],
                     help="N > 1: gradient buckets travel as bfloat16 (DataParallel(grad_compress='bf16'): half the bytes on "
-                         "xGMI, bf16 sums like torch DDP's compression hook); default: fp32, exact")
+                         "xGMI, bf16 sums like torch DDP's compression hook).  Default: fp32 (exact) for --dtype f32 / f32x3; "
+                         "for --dtype bf16 both forms are measured like the buckets and the faster one is taken")
+    ap.add_argument("--dp-autotune-steps", type=int, default=5,
+                    help="N > 1: timed steps per exchange candidate (after 1 untimed step); 0 = no measurement, the defaults "
+                         "(2 buckets, fp32 on the wire)")
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("D3F_DIST_TIMEOUT", "600")),
                     help="N > 1: seconds a rank waits for the rendezvous / the first barrier / any collective before it "
                          "exits non-zero with its rank and the stage it was stuck in (never hangs the job)")
@@ -439,12 +452,21 @@ def extra_workload(args):
     if args.workload == "deepfake":
         from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
         bs = 8
-        lit = LitModule(mode="denoise", batch_size=bs, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=50,
+        swap = args.mode == "swap"
+        # hyper-parameters of denoise_config.yml / swap_config.yml (lambda 3 / 8, ema_beta 0.9999, ema_update_every 1)
+        lit = LitModule(mode=args.mode, batch_size=bs, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=50,
                         cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
-                        noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
-                        std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype,
-                        augment=False).to(dev).train()
+                        noise_exponential_sampling_lambda=8 if swap else 3, mean_a=[0.5] * 3, std_a=[0.5] * 3,
+                        mean_b=[0.5] * 3, std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype,
+                        ema_beta=0.9999, ema_update_every=1, augment=False,
+                        pair_fused={"auto": None, "on": True, "off": False}[args.pair_fused]).to(dev).train()
         opts, _ = lit.configure_optimizers()
+        if swap:
+            # steady state of the 200-epoch phase: past ema_pytorch's update_after_step = 100 warm-up copies, every
+            # update() is the lerp (one launch over the flat parameters + one over the BatchNorm statistics per net)
+            for ema in (lit.ema_model_a, lit.ema_model_b):
+                for _ in range(ema.update_after_step + 2):
+                    ema.update()
         batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i, device=dev), "index": None}
                  for i, k in enumerate("ab")}
         from denoising_diffusion_deep_fake_amd.trainer import optimizer_steps
@@ -459,9 +481,15 @@ def extra_workload(args):
             return optimizer_steps(lit, opts, opt_params, batch, i, True, streams)
         images_per_step = 2 * bs
         fwd_fl, bwd_fl = lit.model_a.conv_flops(bs, args.size, args.size, dev)
-        flops_per_step = 2 * (fwd_fl + bwd_fl)  # two nets, one training step each per combined batch
-        name = (f"d3f train_deep_fake denoise-mode step, two nets, bs={bs} per domain, the two optimizer steps "
-                f"{'overlapped on two streams' if streams else 'one after the other'}")
+        # two nets, one training step each per combined batch; swap mode adds the EMA teacher's forward (SURVEY.md 8d:
+        # 62.36 GFLOP per image at 256x256)
+        flops_per_step = 2 * (fwd_fl + bwd_fl + (fwd_fl if swap else 0))
+        fused = bool(getattr(lit, "pair_fused_active", lambda: False)())
+        name = (f"d3f train_deep_fake {args.mode}-mode step, two nets, bs={bs} per domain, the two optimizer steps "
+                + ("as ONE set of launches (two-net plan)" if fused else
+                   "overlapped on two streams" if streams else "one after the other")
+                + ("; per optimizer: EMA lerp of the other net's teacher, teacher forward (no_grad, train-mode BatchNorm), "
+                   "noise blend, student forward / loss / backward / Adam" if swap else ""))
     else:
         # BASELINE.json configs[4]: 50 sequential eval-mode forwards of a batch of 64 at 256x256, the output fed back
         # as the next input (clamped: the "re-noise" stand-in of SURVEY.md 8d), the denoise step replayed from a
@@ -724,7 +752,14 @@ def main():
     (opt,), _ = lit.configure_optimizers()
     lit.attach_optimizers([opt])
     stage["name"] = "parameter broadcast (DataParallel)"
-    DataParallel(lit.model, opt, buckets=args.dp_buckets, grad_compress=None if args.dp_compress == "none" else args.dp_compress)
+    # exchange candidates (buckets, wire format): what the command line fixed stays fixed, the rest is measured
+    cand_b = [args.dp_buckets] if args.dp_buckets is not None else [2, 4]
+    cand_c = ([None if args.dp_compress == "none" else args.dp_compress] if args.dp_compress is not None
+              else ([None, "bf16"] if args.dtype == "bf16" else [None]))
+    candidates = [(b, c) for c in cand_c for b in cand_b]
+    if args.dp_autotune_steps <= 0:
+        candidates = candidates[:1]
+    dp = DataParallel(lit.model, opt, buckets=candidates[0][0], grad_compress=candidates[0][1])
     if world > 1:
         stage["name"] = "first barrier"
         dist.barrier()
@@ -758,6 +793,30 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     use_events = not args.no_kernel_events
+    # N > 1: the exchange configuration is MEASURED on this job, not assumed (no N > 1 box existed while this was
+    # written): every rank times every candidate over the same steps, one all_reduce(MAX) per candidate gives all ranks
+    # the same table, the first minimum runs the timed region.  N = 1: nothing happens here.
+    chosen, dp_table = candidates[0], None
+    if world > 1 and len(candidates) > 1:
+        from denoising_diffusion_deep_fake_amd.distributed import autotune_exchange
+        tune_i = [0]
+
+        def time_candidate(cand):
+            dp.configure(buckets=cand[0], grad_compress=cand[1])
+            step(args.warmup + tune_i[0])  # untimed: staging buffers, RCCL channels of this bucket size
+            fence()
+            t0 = time.perf_counter()
+            for k in range(args.dp_autotune_steps):
+                step(args.warmup + tune_i[0] + 1 + k)
+            fence()
+            tune_i[0] += 1 + args.dp_autotune_steps
+            return (time.perf_counter() - t0) / args.dp_autotune_steps
+        chosen, table = autotune_exchange(candidates, time_candidate)
+        dp.configure(buckets=chosen[0], grad_compress=chosen[1])
+        step(args.warmup)  # one settling step with the winner
+        dp_table = [{"buckets": c[0], "grad_compress": c[1] or "none", "ms_per_step_max_over_ranks": round(1e3 * t, 3)}
+                    for c, t in table]
+        log(f"dp autotune: {dp_table} -> {chosen}")
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -765,6 +824,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+    # N > 1: what the exchange still costs the optimiser's stream -- the stall inside reducer.wait(), bracketed by HIP
+    # events on that stream, in a pass of its own right after the timed region (an event pair taxes the stream)
+    exposed_ms = None
+    if world > 1:
+        dp.reducer.timing = True
+        for i in range(min(args.steps, 5)):
+            loss = step(args.warmup + args.steps + i)
+        dp.reducer.timing = False
+        mine, nwaits = dp.reducer.exposed_ms()
+        ex = torch.tensor([mine if mine is not None else -1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        exposed_ms = round(float(ex.item()), 4) if nwaits else None
     # Kernel-level roofline figures: HIP events around every launch of a kernel class, in two passes of `diag` steps
     # RIGHT AFTER the timed region (same process, same resident batches, same clocks) -- not inside it: an event pair
     # costs ~8 us of stream time (its marker packets drain the queue), 97 pairs per step would tax `value` by ~2 %.
@@ -832,8 +903,8 @@ def main():
                    "adam_overlap_tail": bool(opt.early_updates > 0),
                    "adam_overlap_tail_steps": int(opt.early_updates),
                    # N > 1: gradient exchange buckets per backward pass; parameter bits equal on every rank after the run
-                   "dp_buckets": args.dp_buckets if world > 1 else None,
-                   "dp_grad_compress": (args.dp_compress if world > 1 else None),
+                   "dp_buckets": chosen[0] if world > 1 else None,
+                   "dp_grad_compress": ((chosen[1] or "none") if world > 1 else None),
                    "replicas_bit_identical": replicas_identical,
                    # what the collective layer saw (None at N=1: no process group, no exchange step)
                    "backend": dist.get_backend() if world > 1 else None,
@@ -846,6 +917,11 @@ def main():
                    "whole_step_conv_tflops": round(whole, 2),
                    "whole_step_frac_of_peak": round(whole / peak, 4)},
     }
+    if world > 1:
+        # the table the ranks agreed on (None: the command line fixed the exchange, or --dp-autotune-steps 0) and the stall
+        # of the optimiser's stream inside reducer.wait() per step, max over ranks (5 steps right after the timed region)
+        out["config"]["dp_autotune"] = dp_table
+        out["config"]["exposed_allreduce_ms"] = exposed_ms
     if use_events and n[0] > 0 and n[1] > 0:
         names = ["conv_igemm_kernel + conv_patch_kernel + conv_winograd_kernel (forward launches)",
                  "conv_igemm_kernel + conv_patch_kernel (data-gradient launches)",

@@ -80,6 +80,35 @@ class BucketAllReducer:
         self.force = force  # issue the collective even for one rank (exercises RCCL on a one-GPU box)
         self.compress = compress
         self._staging = {}   # segment -> bf16 buffer, reused every step
+        # timing = True: wait() measures what the collectives cost the optimiser's stream -- the stall between "this
+        # stream has reached wait()" and "every bucket's all-reduce (and its write-back) is done", i.e. the part of the
+        # exchange that the backward pass did NOT hide.  HIP events on the waiting stream (a work.wait() of the RCCL
+        # backend only orders streams, it does not block the host); host wall time for host-blocking backends (gloo).
+        self.timing = False
+        self._timed = []     # (start event, end event) per wait(), or host seconds
+        self.waits = 0
+
+    def configure(self, compress):
+        """switch the wire format between steps (bench.py's exchange autotune); never while buckets are in flight"""
+        if compress not in (None, "bf16"):
+            raise ValueError(f"BucketAllReducer: compress must be None or 'bf16', got {compress!r}")
+        if self.works:
+            raise RuntimeError("BucketAllReducer.configure() with collectives in flight: call wait() first")
+        self.compress = compress
+
+    def exposed_ms(self, reset=True):
+        """(mean stall per wait() in ms since the last reset, waits measured); synchronises the device"""
+        if not self._timed:
+            return None, 0
+        total = 0.0
+        if torch.cuda.is_available() and not isinstance(self._timed[0], float):
+            torch.cuda.synchronize()
+        for t in self._timed:
+            total += t * 1e3 if isinstance(t, float) else t[0].elapsed_time(t[1])
+        n = len(self._timed)
+        if reset:
+            self._timed = []
+        return total / n, n
 
     def __call__(self, segment, flat_slice):
         if not (self.world_size > 1 or self.force):
@@ -94,11 +123,50 @@ class BucketAllReducer:
         self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, flat_slice))
 
     def wait(self):
+        timed = self.timing and bool(self.works)
+        if timed:
+            import time
+            on_dev = self.works[0][0] is not None and torch.cuda.is_available() and \
+                (dist.get_backend(self.group) == "nccl" if dist.is_initialized() else False)
+            if on_dev:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            t0 = time.perf_counter()
         for w, buf, dst in self.works:
             w.wait()
             if buf is not None:
                 dst.copy_(buf)  # on the stream that called wait() (the optimiser's), behind the collective
+        if timed:
+            if on_dev:
+                e1.record()
+                self._timed.append((e0, e1))
+            else:
+                self._timed.append(time.perf_counter() - t0)
+        self.waits += 1 if self.works else 0
         self.works = []
+
+
+def autotune_exchange(candidates, time_candidate, group=None, device=None):
+    """Pick the data-parallel exchange configuration by MEASUREMENT, identically on every rank.
+
+    candidates: a list of hashable settings (bench.py: (buckets, grad_compress)); time_candidate(c) -> seconds per step of
+    THIS rank with setting c (every rank must run the same number of steps: the steps contain collectives).  Per candidate
+    the ranks' times are combined with ONE all_reduce(MAX) -- the job's step time is its slowest rank's -- so every rank
+    holds the same table and takes the same winner (first minimum: ties go to the earlier candidate).  No rank ever
+    decides from its own clock.  Returns (winner, [(candidate, max-over-ranks seconds)])."""
+    table = []
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi and device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    for cand in candidates:
+        t = float(time_candidate(cand))
+        if multi:
+            tt = torch.tensor([t], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+            t = float(tt.item())
+        table.append((cand, t))
+    best = min(range(len(table)), key=lambda i: (table[i][1], i))
+    return table[best][0], table
 
 
 class DataParallel:
@@ -126,6 +194,15 @@ class DataParallel:
             model.set_grad_sync(self.reducer, buckets)
             optimizer.grad_scale = 1.0 / self.world_size
             optimizer.before_step = self.reducer.wait
+
+    def configure(self, buckets=None, grad_compress="keep"):
+        """change the exchange between steps: buckets (as the constructor's) and / or the wire format (None | "bf16")"""
+        if buckets is not None:
+            self.buckets = buckets
+            if self.world_size > 1:
+                self.model.set_grad_sync(self.reducer, buckets)
+        if grad_compress != "keep":
+            self.reducer.configure(grad_compress)
 
 
 def shard_indices(n, world_size, rank):

@@ -250,3 +250,60 @@ def test_bench_rank_without_peers_exits_instead_of_hanging():
     assert time.monotonic() - t0 < 90
     assert "rank 1" in out.stderr, out.stderr[-1500:]
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _worker_autotune(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from denoising_diffusion_deep_fake_amd.distributed import BucketAllReducer, autotune_exchange, init_process_group
+    init_process_group("gloo")
+    # every rank's OWN clock prefers a different candidate: rank r sees candidate r as the fastest.  The job's time is the
+    # slowest rank's, so the table every rank must hold is the max over ranks -- and the winner the candidate whose WORST
+    # rank is best, which no rank would have picked from its own numbers.
+    candidates = [(2, None), (4, None), (2, "bf16"), (4, "bf16")]
+    local = {c: 10.0 + 3.0 * i + (-9.5 if i == rank else 0.0) + (5.0 if (i == 2 and rank == 3) else 0.0)
+             for i, c in enumerate(candidates)}
+    seen = []
+
+    def time_candidate(c):
+        seen.append(c)
+        return local[c]
+    winner, table = autotune_exchange(candidates, time_candidate)
+    # the exposed-exchange clock of the reducer (host wall time over gloo): one wait() measured per step
+    red = BucketAllReducer()
+    red.timing = True
+    flat = torch.ones(1000) * (rank + 1)
+    for _ in range(3):
+        red(0, flat[500:])
+        red(1, flat[:500])
+        red.wait()
+    ms, n = red.exposed_ms()
+    ret[rank] = (winner, [(c, round(t, 6)) for c, t in table], seen == candidates, n, ms is not None and ms >= 0.0,
+                 red.exposed_ms() == (None, 0))
+    dist.destroy_process_group()
+
+
+def test_exchange_autotune_every_rank_takes_the_same_winner_world4():
+    """bench.py --gpus N picks gradient buckets / wire format by measurement (distributed.autotune_exchange): four ranks whose
+    own clocks disagree must end with the SAME table (max over ranks per candidate) and the same winner."""
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn_with_deadline(_worker_autotune, (world, _free_port(), ret), world, seconds=120)
+    winners = {ret[r][0] for r in range(world)}
+    tables = {tuple(ret[r][1]) for r in range(world)}
+    assert len(winners) == 1 and len(tables) == 1, (winners, tables)
+    table = dict(ret[0][1])
+    # max over ranks: candidate i costs 10 + 3 i on every rank but its own fan (and candidate 2 costs rank 3 five more)
+    assert table == {(2, None): 10.0, (4, None): 13.0, (2, "bf16"): 21.0, (4, "bf16"): 19.0}
+    assert winners == {(2, None)}
+    for r in range(world):
+        assert ret[r][2] and ret[r][3] == 3 and ret[r][4] and ret[r][5], ret[r]
+
+
+def test_exchange_autotune_single_process_and_ties():
+    from denoising_diffusion_deep_fake_amd.distributed import autotune_exchange
+    winner, table = autotune_exchange([(2, None), (4, None)], lambda c: 1.0)   # a tie goes to the earlier candidate
+    assert winner == (2, None) and [t for _, t in table] == [1.0, 1.0]
+    winner, _ = autotune_exchange([(2, None), (4, None)], lambda c: {2: 2.0, 4: 1.5}[c[0]])
+    assert winner == (4, None)

@@ -211,7 +211,7 @@ def test_bench_self_launch_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "4",
-           "--size", "64"]
+           "--size", "64", "--dp-buckets", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -219,9 +219,12 @@ def test_bench_self_launch_two_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 5 and res["config"]["parallelism"] == "dp2"
     assert res["value"] > 0 and res["roofline"]["frac"] is not None and res["roofline"]["launches"] > 0
-    # the default exchange: 2 buckets, every rank seen, replicas bit-identical after the timed steps
+    # the exchange the command line fixed: 2 buckets, nothing measured; every rank seen, replicas bit-identical after the run
     assert res["config"]["dp_buckets"] == 2 and res["config"]["ranks_seen"] == 2
+    assert res["config"]["dp_autotune"] is None and res["config"]["dp_grad_compress"] == "none"
     assert res["config"]["replicas_bit_identical"] is True
+    # the stall of the optimiser's stream inside reducer.wait(), measured on 5 steps behind the timed region
+    assert res["config"]["exposed_allreduce_ms"] is not None and res["config"]["exposed_allreduce_ms"] >= 0.0
 
 
 def _syncbn_worker(rank, world, port, ret):
@@ -311,11 +314,11 @@ def test_bench_self_launch_four_ranks_replicas_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    # one launch (~35 s with four ranks on one card): the 4-bucket exchange; the default 2 buckets are rehearsed by the
-    # two-rank self launch above and by the gloo world-8 test on the CPU
-    buckets = 4
+    # one launch (~40 s with four ranks on one card), the exchange left to the run's own measurement as in the driver's
+    # scaling run: 2 and 4 buckets timed behind the warm-up, one all_reduce(MAX) per candidate, the faster one runs the
+    # timed region (the agreement logic itself: tests/test_cpu_distributed.py, gloo world 4)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--batch", "4",
-           "--size", "64", "--dp-buckets", str(buckets), "--dist-timeout", "120"]
+           "--size", "64", "--dp-autotune-steps", "2", "--dist-timeout", "120"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -323,7 +326,12 @@ def test_bench_self_launch_four_ranks_replicas_identical():
     res = json.loads(lines[0])
     cfg = res["config"]
     assert res["n_gpus"] == 4 and cfg["ranks_seen"] == 4 and cfg["global_batch"] == 16 and cfg["parallelism"] == "dp4"
-    assert cfg["dp_buckets"] == buckets and cfg["replicas_bit_identical"] is True
+    table = cfg["dp_autotune"]
+    assert [(t["buckets"], t["grad_compress"]) for t in table] == [(2, "none"), (4, "none")]
+    assert all(t["ms_per_step_max_over_ranks"] > 0 for t in table)
+    best = min(table, key=lambda t: t["ms_per_step_max_over_ranks"])
+    assert cfg["dp_buckets"] == best["buckets"] and cfg["dp_grad_compress"] == "none"
+    assert cfg["exposed_allreduce_ms"] is not None and cfg["replicas_bit_identical"] is True
     assert res["value"] > 0 and res["scaling"] == "weak"
 
 
