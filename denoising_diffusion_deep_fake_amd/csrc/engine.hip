@@ -504,15 +504,34 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
 }
 
 // ------------------------------------------------------------------------------------------
+// ONE side stream per device for every engine of the process.  A module holds several engines -- train_deep_fake's swap
+// mode runs four networks (two students, two EMA teachers: d3f/train_deep_fake/lit_module.py:36-40), each with a plan per
+// shape -- and they run one after the other on the caller's stream; a side stream per ENGINE gave that step five streams,
+// and with more than three streams in use the ROCm 7 runtime (four hardware queues by default) makes every launch of the
+// step slow: swap mode 36.2 ms per combined batch with per-engine streams, 14.1 ms with two streams in all, 13.9 ms with
+// GPU_MAX_HW_QUEUES=2 (profiles/README.md, round 6).  Sharing only ever ADDS ordering between engines, never removes any.
+static int shared_side_stream(hipStream_t* out) {
+  constexpr int MAXDEV = 64;
+  static hipStream_t streams[MAXDEV] = {};
+  int dev = 0;
+  D3F_HIP(hipGetDevice(&dev));
+  D3F_CHECK(dev >= 0 && dev < MAXDEV, "side stream: device index %d", dev);
+  if (streams[dev] == nullptr) {
+    // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
+    // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured).
+    // A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
+    // left to the caller's stream) was tried and halves the throughput on this platform.
+    int least = 0, greatest = 0;
+    D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    D3F_HIP(hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least));
+  }
+  *out = streams[dev];  // lives as long as the process (engines come and go; nothing is ever left running on it unjoined)
+  return 0;
+}
+
 int UnetEngine::ensure_streams() const {
   if (side_ != nullptr) return 0;
-  // lowest priority: the weight gradients fill the machine behind the dependent chain on the caller's stream
-  // (BatchNorm backward -> data gradient), whose workgroups should get freed CUs first (+0.5-1 % measured).
-  // A CU mask on this stream (hipExtStreamCreateWithCUMask, every 2nd..8th CU
-  // left to the caller's stream) was tried and halves the throughput on this platform.
-  int least = 0, greatest = 0;
-  D3F_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  D3F_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, least));
+  if (int rc = shared_side_stream(&side_)) return rc;
   D3F_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_seg_, hipEventDisableTiming));
   D3F_HIP(hipEventCreateWithFlags(&ev_pack_in_, hipEventDisableTiming));
@@ -898,7 +917,7 @@ UnetEngine::~UnetEngine() {
   if (ev_pack_in_) (void)hipEventDestroy(ev_pack_in_);
   if (ev_pack_done_) (void)hipEventDestroy(ev_pack_done_);
   if (ev_pack_mid_) (void)hipEventDestroy(ev_pack_mid_);
-  if (side_) (void)hipStreamDestroy(side_);
+  // (side_ is the process-wide stream of this device: not ours to destroy)
 }
 
 // Backward of segments [seg_begin, seg_end).  Per unit: BN backward (writes the unit's dY) -> {weight gradient,
