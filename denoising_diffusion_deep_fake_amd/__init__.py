@@ -4,6 +4,6 @@
 all device work happens in hand-written gfx950 kernels behind include/d3f_hip.h.
 """
 from ._lib import D3FError, F32, BF16  # noqa: F401
-from .unet import Unet  # noqa: F401
+from .unet import Unet, UnetPair  # noqa: F401
 
 __version__ = "0.1.0"

@@ -37,6 +37,12 @@ PROTOTYPES = {
     "d3f_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3f_unet_create": (_i, [C.c_char_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "d3f_unet_destroy": (_i, [_p]),
+    "d3f_unet_create_nets": (_i, [C.c_char_p, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_p)]),
+    "d3f_unet_nets": (_i, [_p]),
+    "d3f_unet_net_workspace_stride": (_sz, [_p]),
+    "d3f_unet_pair_pack_weights": (_i, [_p, C.POINTER(_p), _p, _p]),
+    "d3f_unet_pair_forward": (_i, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _p, _p]),
+    "d3f_unet_pair_backward": (_i, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _p, _i, _i, _i, _p]),
     "d3f_unet_num_params": (_i, [_p]),
     "d3f_unet_param_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(C.c_int32), C.POINTER(_i), C.POINTER(_i64)]),
     "d3f_unet_param_floats": (_i64, [_p]),
@@ -177,3 +183,8 @@ def ptr(t):
     if t is None:
         return None
     return C.c_void_p(t.data_ptr())
+
+
+def ptr2(a, b):
+    """the `T* const x[2]` argument of the pair entry points: the two networks' buffers"""
+    return (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())

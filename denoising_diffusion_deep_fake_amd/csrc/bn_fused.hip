@@ -116,8 +116,15 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
     const T* __restrict__ y, const T* __restrict__ res, const T* __restrict__ yr,
     const float* __restrict__ scale_r, const float* __restrict__ shift_r, int relu, T* __restrict__ out,
-    long rows, long rows_per_block) {
+    long rows, long rows_per_block, NetSplit ns) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): blockIdx.z = net
+    net_shift(stats, ns.ws); net_shift(gamma, ns.par); net_shift(beta, ns.par);
+    net_shift(running_mean, ns.bn); net_shift(running_var, ns.bn);
+    net_shift(mean_o, ns.ws); net_shift(invstd_o, ns.ws); net_shift(scale_o, ns.ws); net_shift(shift_o, ns.ws);
+    net_shift(y, ns.ws); net_shift(res, ns.ws); net_shift(yr, ns.ws); net_shift(scale_r, ns.ws); net_shift(shift_r, ns.ws);
+    net_shift(out, ns.ws);
+  }
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[2][BNF_SC];
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 // re-swept in round 4 with two batches in flight: fp32 7.87 / 7.91 / 7.94 / 7.94 / 8.02 ms at 256 / 384 / 512 / 768 / 1024,
 // bf16 4.09 / 4.09 / 4.12 / 4.18 at 384 / 512 / 768 / 1024 -- unchanged optimum; 512 / 768 / 1024 only for the tensors of 32 MB
 // and more (stem, decoder block 3): 7.89 / 7.91 / 7.90 against 7.87 / 7.89 -- no gain either)
-static long rows_per_block_for(long rows, int slabs, int dtype) {
-  const long wgs = dtype == D3F_F32 ? 256 : 512;
+static long rows_per_block_for(long rows, int slabs, int dtype, int plan_nets) {
+  const long wgs = (dtype == D3F_F32 ? 256 : 512) / nets_of(plan_nets);  // (two networks in one launch share the count)
   long rb = std::max(1L, wgs / slabs);
   long rpb = (rows + rb - 1) / rb;
   rpb = (rpb + 31) / 32 * 32;
@@ -226,18 +233,20 @@ int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C
                              const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, float* scale, float* shift,
                              const void* y, const void* res, const void* yr, const float* scale_r,
-                             const float* shift_r, int relu, void* out, long rows, hipStream_t stream) {
+                             const float* shift_r, int relu, void* out, long rows, hipStream_t stream,
+                             const NetSplit* ns, int plan_nets) {
   D3F_CHECK(bn_fused_finalize_ok(dtype, stat_rows, C), "bn_finalize_apply: C=%d, %d partial rows", C, stat_rows);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
-  const long rpb = rows_per_block_for(rows, slabs, dtype);
-  const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
+  const long rpb = rows_per_block_for(rows, slabs, dtype, plan_nets);
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs, (unsigned)nv.nets);
   const bool has2 = res != nullptr || yr != nullptr;
   auto go = [&](auto kernel, auto* typed) {
     typedef std::remove_pointer_t<decltype(typed)> T;
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, stats, stat_rows, C, Cpad, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, mean, invstd, scale, shift, (const T*)y, (const T*)res,
-                       (const T*)yr, scale_r, shift_r, relu, (T*)out, rows, rpb);
+                       (const T*)yr, scale_r, shift_r, relu, (T*)out, rows, rpb, nv);
   };
   if (dtype == D3F_F32) {
     if (has2) go(bn_finalize_apply_kernel<float, true>, (float*)nullptr);
@@ -264,8 +273,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(
     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, const T* __restrict__ dA,
     const T* __restrict__ a, const T* __restrict__ y, T* __restrict__ dy, T* __restrict__ dres,
     long rows, long rows_per_block, const float* __restrict__ mask_scale,
-    const float* __restrict__ mask_shift) {
+    const float* __restrict__ mask_shift, NetSplit ns) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): blockIdx.z = net
+    net_shift(partial, ns.ws); net_shift(gamma, ns.par); net_shift(mean, ns.ws); net_shift(invstd, ns.ws);
+    net_shift(dgamma, ns.grad); net_shift(dbeta, ns.grad); net_shift(coef, ns.ws);
+    net_shift(dA, ns.ws); net_shift(a, ns.ws); net_shift(y, ns.ws); net_shift(dy, ns.ws); net_shift(dres, ns.ws);
+    net_shift(mask_scale, ns.ws); net_shift(mask_shift, ns.ws);
+  }
   __shared__ double red[16][64];
   __shared__ double tot[64];
   __shared__ float cf[3][BNF_SC];
@@ -367,19 +382,20 @@ int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, i
                                  const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                  int accumulate, float* coef, const void* dA, const void* a, const void* y, void* dy,
                                  void* dres, int dres_acc, long rows, hipStream_t stream, const float* mask_scale,
-                                 const float* mask_shift) {
+                                 const float* mask_shift, const NetSplit* ns, int plan_nets) {
   D3F_CHECK(bn_fused_finalize_ok(dtype, nblocks, C), "bn_bwd_finalize_apply: C=%d, %d partial rows", C, nblocks);
   if (rows == 0) return 0;
   const int slabs = C / BNF_SC;
-  const long rpb = rows_per_block_for(rows, slabs, dtype);
-  const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs);
+  const long rpb = rows_per_block_for(rows, slabs, dtype, plan_nets);
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)slabs, (unsigned)nv.nets);
   const bool from_a = mask_scale == nullptr && a != nullptr;
   const bool rd_dres = dres != nullptr && dres_acc;
   auto go = [&](auto kernel, auto* typed) {
     typedef std::remove_pointer_t<decltype(typed)> T;
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, partial, nblocks, C, (double)count, gamma, mean, invstd, dgamma,
                        dbeta, accumulate, coef, (const T*)dA, (const T*)a, (const T*)y, (T*)dy, (T*)dres, rows, rpb,
-                       mask_scale, mask_shift);
+                       mask_scale, mask_shift, nv);
   };
   auto pick = [&](auto* typed) {
     typedef std::remove_pointer_t<decltype(typed)> T;

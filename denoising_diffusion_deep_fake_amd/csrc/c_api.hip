@@ -223,9 +223,67 @@ int d3f_unet_create(const char* encoder_name, int in_channels, int classes, int 
   *out = h;
   return 0;
 }
+int d3f_unet_create_nets(const char* encoder_name, int in_channels, int classes, int B, int H, int W, int dtype,
+                         int nets, int plan_nets, d3f_unet_t* out) {
+  D3F_CHECK(out != nullptr && encoder_name != nullptr, "unet_create_nets: null argument");
+  d3f_unet* h = new (std::nothrow) d3f_unet();
+  D3F_CHECK(h != nullptr, "unet_create_nets: out of host memory");
+  const int rc = h->e.build(encoder_name, in_channels, classes, B, H, W, dtype, nets, plan_nets);
+  if (rc != 0) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
 int d3f_unet_destroy(d3f_unet_t h) {
   delete h;
   return 0;
+}
+int d3f_unet_nets(d3f_unet_t h) { return h ? h->e.nets : -1; }
+size_t d3f_unet_net_workspace_stride(d3f_unet_t h) { return h ? h->e.net_ws_stride : 0; }
+
+// the second network's buffers as byte offsets from the first one's (engine.h, NetIO)
+static inline long byte_delta(const void* b, const void* a) {
+  return (long)(reinterpret_cast<const char*>(b) - reinterpret_cast<const char*>(a));
+}
+int d3f_unet_pair_pack_weights(d3f_unet_t h, const float* const params[2], void* workspace, void* stream) {
+  D3F_CHECK(h && params && params[0] && params[1] && workspace, "pair_pack_weights: null argument");
+  D3F_CHECK(h->e.nets == 2, "pair_pack_weights: the handle is not a pair (d3f_unet_create_nets(..., nets = 2, ...))");
+  NetIO io;
+  io.params = byte_delta(params[1], params[0]);
+  return h->e.pack_weights(params[0], workspace, (hipStream_t)stream, &io);
+}
+int d3f_unet_pair_forward(d3f_unet_t h, const float* const params[2], float* const bnstats[2], const float* const x[2],
+                          float* const out[2], void* workspace, void* stream) {
+  D3F_CHECK(h && params && bnstats && x && out && workspace, "pair_forward: null argument");
+  D3F_CHECK(h->e.nets == 2, "pair_forward: the handle is not a pair (d3f_unet_create_nets(..., nets = 2, ...))");
+  for (int n = 0; n < 2; ++n)
+    D3F_CHECK(params[n] && bnstats[n] && x[n] && out[n], "pair_forward: null buffer of network %d", n);
+  D3F_CHECK(params[0] != params[1] && bnstats[0] != bnstats[1] && out[0] != out[1],
+            "pair_forward: the two networks must own distinct parameters, statistics and outputs");
+  NetIO io;
+  io.params = byte_delta(params[1], params[0]);
+  io.bnstats = byte_delta(bnstats[1], bnstats[0]);
+  io.x = byte_delta(x[1], x[0]);
+  io.out = byte_delta(out[1], out[0]);
+  return h->e.forward(params[0], bnstats[0], x[0], out[0], workspace, 1, (hipStream_t)stream, &io);
+}
+int d3f_unet_pair_backward(d3f_unet_t h, const float* const params[2], const float* const grad_out[2],
+                           float* const grads[2], void* workspace, int seg_begin, int seg_end, int join, void* stream) {
+  D3F_CHECK(h && params && grad_out && grads && workspace, "pair_backward: null argument");
+  D3F_CHECK(h->e.nets == 2, "pair_backward: the handle is not a pair (d3f_unet_create_nets(..., nets = 2, ...))");
+  for (int n = 0; n < 2; ++n)
+    D3F_CHECK(params[n] && grad_out[n] && grads[n], "pair_backward: null buffer of network %d", n);
+  D3F_CHECK(grads[0] != grads[1], "pair_backward: the two networks must own distinct gradient buffers");
+  D3F_CHECK(seg_begin >= 0 && seg_end <= h->e.num_segments && seg_begin <= seg_end,
+            "pair_backward: segments [%d,%d)", seg_begin, seg_end);
+  NetIO io;
+  io.params = byte_delta(params[1], params[0]);
+  io.grads = byte_delta(grads[1], grads[0]);
+  io.dout = byte_delta(grad_out[1], grad_out[0]);
+  return h->e.backward(params[0], grad_out[0], grads[0], workspace, seg_begin, seg_end, (hipStream_t)stream, join ? 1 : 0,
+                       &io);
 }
 int d3f_unet_num_params(d3f_unet_t h) { return h ? (int)h->e.params.size() : -1; }
 int d3f_unet_param_info(d3f_unet_t h, int i, char* name, int name_cap, int32_t shape[4], int* ndim,
@@ -257,11 +315,13 @@ double d3f_unet_backward_flops(d3f_unet_t h) { return h ? h->e.bwd_flops : 0.0; 
 
 int d3f_unet_pack_weights(d3f_unet_t h, const float* params, void* workspace, void* stream) {
   D3F_CHECK(h && params && workspace, "pack_weights: null argument");
+  D3F_CHECK(h->e.nets == 1, "pack_weights: a pair handle takes d3f_unet_pair_pack_weights");
   return h->e.pack_weights(params, workspace, (hipStream_t)stream);
 }
 int d3f_unet_forward(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
                      void* workspace, int training, void* stream) {
   D3F_CHECK(h && params && bnstats && x && out && workspace, "unet_forward: null argument");
+  D3F_CHECK(h->e.nets == 1, "unet_forward: a pair handle takes d3f_unet_pair_forward");
   return h->e.forward(params, bnstats, x, out, workspace, training, (hipStream_t)stream);
 }
 int d3f_unet_forward_graph(d3f_unet_t h, const float* params, float* bnstats, const float* x, float* out,
@@ -303,6 +363,7 @@ int d3f_unet_segment_range(d3f_unet_t h, int segment, int64_t* begin, int64_t* e
 int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
                       void* workspace, int seg_begin, int seg_end, void* stream) {
   D3F_CHECK(h && params && grad_out && grads && workspace, "unet_backward: null argument");
+  D3F_CHECK(h->e.nets == 1, "unet_backward: a pair handle takes d3f_unet_pair_backward");
   D3F_CHECK(seg_begin >= 0 && seg_end <= h->e.num_segments && seg_begin <= seg_end,
             "unet_backward: segments [%d,%d)", seg_begin, seg_end);
   return h->e.backward(params, grad_out, grads, workspace, seg_begin, seg_end, (hipStream_t)stream);
@@ -310,6 +371,7 @@ int d3f_unet_backward(d3f_unet_t h, const float* params, const float* grad_out, 
 int d3f_unet_backward_nojoin(d3f_unet_t h, const float* params, const float* grad_out, float* grads,
                              void* workspace, int seg_begin, int seg_end, void* stream) {
   D3F_CHECK(h && params && grad_out && grads && workspace, "unet_backward_nojoin: null argument");
+  D3F_CHECK(h->e.nets == 1, "unet_backward_nojoin: a pair handle takes d3f_unet_pair_backward(join = 0)");
   D3F_CHECK(seg_begin >= 0 && seg_end <= h->e.num_segments && seg_begin <= seg_end,
             "unet_backward_nojoin: segments [%d,%d)", seg_begin, seg_end);
   return h->e.backward(params, grad_out, grads, workspace, seg_begin, seg_end, (hipStream_t)stream, 0);

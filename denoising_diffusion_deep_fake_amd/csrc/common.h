@@ -103,6 +103,32 @@ __device__ __forceinline__ void chain_priority() {
 #endif
 }
 
+// ---- two networks, one launch -----------------------------------------------------------------------------------
+// train_deep_fake's denoise mode steps two INDEPENDENT networks of identical shape per batch (model_a on domain a, model_b
+// on domain b: d3f/train_deep_fake/lit_module.py:142-181) with 8 images each -- half of what fills the chip.  A launch of
+// the pair engine carries both: gridDim.z = nets x (the kernel's own z extent), and a workgroup of net 1 adds the byte
+// offsets below to its pointers (the second network's copy of the workspace, its parameters, gradients, running
+// statistics and boundary tensors).  Nothing else differs between the two halves of the grid, so the results are bit for
+// bit those of the same plan run net by net.
+struct NetSplit {
+  int nets;   // 1 (the offsets are unused) or 2
+  long ws;    // workspace tensors: activations, packed weights, statistics rows, coefficients, slabs, scratch
+  long par;   // flat parameter buffer
+  long grad;  // flat gradient buffer
+  long bn;    // flat BatchNorm running statistics
+  long in;    // NCHW boundary input of the launch (the forward's x, the backward's output gradient)
+  long out;   // NCHW boundary output (the forward's prediction)
+};
+static inline int nets_of(int n) { return n > 1 ? n : 1; }
+static inline NetSplit net_split_or_single(const NetSplit* ns) {
+  NetSplit one{};
+  one.nets = 1;
+  return (ns != nullptr && ns->nets > 1) ? *ns : one;
+}
+template <typename P> __device__ __forceinline__ void net_shift(P& p, long bytes) {
+  if (p != nullptr) p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;    // elements per 16-byte vector
@@ -201,7 +227,25 @@ struct ConvParams {
                        // a patch kernel takes the launch -- the plan clears it otherwise and the caller reduces itself
   // (9 / 10 / 11: conv_pres_kernel for 64 / 128 / 256 channels, conv_pres.hip)
   int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
+  // two networks in one launch (NetSplit): grid.z = nets * nz; a workgroup of net 1 shifts every pointer above by net_ws,
+  // except out0 (net_out0: the NCHW prediction of CONV_HEAD_NCHW lives outside the workspace) and scale (net_scale: the
+  // head's bias is a parameter).  plan_nets (set before the plan): the tile / split-K / patch-kernel choices count the
+  // workgroups of plan_nets networks, so that a single engine planned with plan_nets = 2 runs exactly the pair's kernels.
+  int nets, plan_nets;
+  long net_ws, net_out0, net_scale;
 };
+// the launch description as net `net` (blockIdx.z / nz) sees it
+__device__ __forceinline__ ConvParams conv_params_of_net(const ConvParams& pin, int net) {
+  ConvParams p = pin;
+  if (net != 0) {
+    net_shift(p.src0, p.net_ws); net_shift(p.src1, p.net_ws); net_shift(p.w, p.net_ws);
+    net_shift(p.out0, p.net_out0); net_shift(p.out1, p.net_ws);
+    net_shift(p.stats, p.net_ws); net_shift(p.scale, p.net_scale); net_shift(p.shift, p.net_ws);
+    net_shift(p.res, p.net_ws); net_shift(p.partial, p.net_ws);
+    net_shift(p.bn_y, p.net_ws); net_shift(p.bn_coef, p.net_ws); net_shift(p.bn_partial, p.net_ws); net_shift(p.bn_a, p.net_ws);
+  }
+  return p;
+}
 
 struct ConvTile {
   int BM, BN;
@@ -276,7 +320,18 @@ struct WgradParams {
   int slab_taps;  // taps per slab row block: KH*KW, or 16 folded taps
   int Mi, Hc, Wc; // pixel grid the k-loop iterates: (M, Ho, Wo), or one parity class (M/4, H0s, W0s)
   int step_img, step_row, step_col;  // one k-chunk (32 pixels) as whole images + rows + columns of that grid
+  // two networks in one launch (NetSplit): grid.z = nets; net 1 shifts dy / src0 / src1 / partial by net_ws.  plan_nets
+  // (set before the plan): the slab count aims at the workgroup target of the WHOLE launch of plan_nets networks.
+  int nets, plan_nets;
+  long net_ws;
 };
+__device__ __forceinline__ WgradParams wgrad_params_of_net(const WgradParams& pin, int net) {
+  WgradParams p = pin;
+  if (net != 0) {
+    net_shift(p.dy, p.net_ws); net_shift(p.src0, p.net_ws); net_shift(p.src1, p.net_ws); net_shift(p.partial, p.net_ws);
+  }
+  return p;
+}
 enum WgradPart : int { WG_WHOLE = 0, WG_CLASS = 1, WG_SKIP = 2 };
 // fills splits / tiles / extents for one launch; returns 0
 int wgrad_plan(WgradParams& p, int dtype);
@@ -297,6 +352,8 @@ struct WgradReduceJob {
 struct WgradReduceBatch {
   WgradReduceJob job[WG_BATCH];
   int n = 0, blocks = 0, lds = 0;
+  int nets = 1;               // two networks (NetSplit): grid.y = nets; net 1 reads its slabs at + net_ws, writes dw at + net_grad
+  long net_ws = 0, net_grad = 0;
 };
 int wgrad_reduce_batch_add(WgradReduceBatch& tb, const float* partial, int splits, int CoutP, int Cout, int Cin,
                            int CinRealPart, int CinRealTotal, int c_off, int KH, int KW, int fold, float* dw);
@@ -316,6 +373,6 @@ int wgrad_layer_launch(const WgradLayer& L, const void* dy, const void* src0, co
 // the passes' launches only; their reduce jobs are appended to `tb` for wgrad_reduce_batch_launch on the same stream
 int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                                 float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
-                                hipStream_t stream);
+                                hipStream_t stream, const NetSplit* ns = nullptr);
 
 }  // namespace d3f

@@ -235,8 +235,11 @@ __device__ __forceinline__ long par_out_row(const ConvParams& p, int py, int px,
 // x0 at (j + py - 1 + a, i + px - 1 + b), segment B: the usual 3x3 taps on the skip tensor x1 -- 4*C0 + 9*C1
 // multiply-adds per output instead of 9*(C0 + C1).
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool SMALLC, int FAST, bool X3>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams pin) {
   chain_priority();
+  // two networks in one launch (common.h, NetSplit): blockIdx.z = net * nz + class
+  const int net = (pin.nets > 1 && (int)blockIdx.z >= pin.nz) ? 1 : 0;
+  const ConvParams p = conv_params_of_net(pin, net);
   constexpr int VE = Elem<T>::VE, BKE = Elem<T>::BKE;
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / MT, FN = TN / MT;
   constexpr int NVA = BM * 8 / 256;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int wm = wmn / WGN, wn = wmn % WGN;
   // Workgroups in plain dispatch order: an XCD-aware remap (every XCD a contiguous range of tiles) cut this kernel's
   // L2-miss traffic by 12 % but made it 2 % SLOWER (bands of unequal length per XCD; profiles/README.md round 2)
-  const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z - (unsigned)(net * p.nz);
   const int tile_n = (int)bx % p.tiles_n, tile_m = (int)bx / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int chunk = tid & 7, rbase = tid >> 3;
@@ -1321,8 +1324,9 @@ constexpr int SK_ROWS = 8;   // rows per reduce workgroup (small: the reduce is 
 constexpr int SK_MAX = 8;    // upper bound of splitk (plan)
 
 template <typename T>
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams pin) {
   chain_priority();
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   __shared__ float red[256 * 4 * 2];
   const int VC = p.Cout / 4;   // 16-byte vectors per row; 256 % VC == 0 (plan)
   const int RP = 256 / VC;     // rows per pass
@@ -1448,7 +1452,8 @@ static ConvTile pick_tile(const ConvParams& p, bool x3, bool bf16 = false) {
   // prefer the biggest tile that still gives >= 2 blocks per CU; small problems fall to 64x64
   const long M = p.M;
   const int nz = (p.par == 1 || p.par == 3) ? 4 : 1;  // output-parity classes share the launch
-  auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn) * nz; };
+  const int pn = nets_of(p.plan_nets);  // two networks share the launch: their workgroups count together
+  auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn) * nz * pn; };
   if (co % 128 == 0 && blocks(128, 128) >= 512) return {128, 128};
   if (blocks(128, 64) >= 512) return {128, 64};
   // deep layers (few thousand rows): tiles with an in-workgroup k split keep >= ~2 workgroups per CU without
@@ -1535,7 +1540,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   p.splitk = 1;
   p.stat_rows = p.nz * p.tiles_m;
   // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop
-  const long base = (long)p.tiles_m * p.tiles_n * p.nz;
+  const long base = (long)p.tiles_m * p.tiles_n * p.nz * nets_of(p.plan_nets);
   const int nk = p.Kpad / bke;
   const int vc = p.Cout / 4;
   static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob
@@ -1559,7 +1564,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool X3>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, (unsigned)p.nz), block(256);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, (unsigned)(p.nz * nets_of(p.nets))), block(256);
   static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
   const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
   if (p.par == 3)
@@ -1625,7 +1630,7 @@ int conv_igemm_launch(const ConvParams& p, int dtype, hipStream_t stream) {
   // average is the number rocprofv3's kernel trace reports for the same kernel
   if (prof) prof_end(stream);
   if (rc == 0 && q.splitk > 1) {
-    const dim3 grid((unsigned)cdiv((long)q.nz * q.M, SK_ROWS)), block(256);
+    const dim3 grid((unsigned)cdiv((long)q.nz * q.M, SK_ROWS), 1, (unsigned)nets_of(q.nets)), block(256);
     if (dtype != D3F_BF16)
       hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, grid, block, 0, stream, q);
     else

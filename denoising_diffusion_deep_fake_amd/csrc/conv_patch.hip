@@ -39,11 +39,7 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
   // bf16, 32 channels -> <= 32 filters (round 5: decoder block 3 conv2 forward + data gradient at 128x128): a pixel is
   // 64 bytes like fp32 x 16 channels, so the staged image is the fp32 one byte for byte; one v_mfma_f32_16x16x32_bf16
   // contracts a whole tap
-#ifdef D3F_NO_PATCH32  // A/B builds only (make EXTRA=-DD3F_NO_PATCH32): the implicit GEMM for these layers, as before round 5
-  const bool wide = false;
-#else
   const bool wide = p.C0 == 32 && dtype == D3F_BF16 && p.mode != CONV_HEAD_NCHW;
-#endif
   // C0 == 8, bf16: the head's data gradient in bf16 storage (3 channels in one 16-byte vector), staged as 16 channels
   const bool cin_ok = p.C0 == 16 || wide || (p.C0 == 4 && p.mode == CONV_DGRAD && dtype == D3F_F32) ||
                       (p.C0 == 8 && p.mode == CONV_DGRAD && dtype == D3F_BF16);
@@ -72,7 +68,8 @@ bool conv_patch_applies(const ConvParams& p, int dtype) {
 // fp32 C tile and stores at half resolution -- the full-resolution scratch tensor (67 MB written + read), the sum2x2
 // launch and the separate BatchNorm-backward reduce of the consumer (its partial sums ride in this epilogue) are gone.
 template <typename T, int CIN, int BN, bool UP = false, int CSRC = CIN, bool SUM2 = false>
-__global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_patch_kernel(const ConvParams pin) {
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   chain_priority();
   constexpr bool BF = sizeof(T) == 2;
   // W64: bf16 x 32 channels -- 64-byte pixels, 32 filters (decoder block 3 conv2)
@@ -525,7 +522,8 @@ bool conv_stem_applies(const ConvParams& p, int dtype) {
          (p.Ho % ST_PH) == 0 && (p.Wo % ST_PW) == 0 && p.Kpad >= 49 * 4;
 }
 
-__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams pin) {
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   chain_priority();
   constexpr int PH = ST_PH, PW = ST_PW, BN = ST_BN;
   constexpr int PR = 2 * PH + 5, PC = 2 * PW + 5;  // 21 x 69 input pixels
@@ -692,7 +690,8 @@ bool conv_stem_bf16_applies(const ConvParams& p, int dtype) {
          (p.Ho % ST_PH) == 0 && (p.Wo % ST_PW) == 0 && p.Kpad >= 49 * 8;
 }
 
-__global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_stem_bf16_kernel(const ConvParams pin) {
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   chain_priority();
   constexpr int PH = ST_PH, PW = ST_PW, BN = ST_BN;
   constexpr int PR = 2 * PH + 5, PC = 2 * PW + 5;   // 21 x 69 input pixels
@@ -866,8 +865,9 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
   if (p.patch == 2 || p.patch == 8) {
     D3F_CHECK(p.tiles_m == p.B * (p.Ho / ST_PH) * (p.Wo / ST_PW) && p.tiles_n == p.Cout / ST_BN && p.C0 == (p.patch == 8 ? 8 : 4),
               "conv: stem patch params were not planned");
-    if (p.patch == 8) hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
+    const dim3 gs((unsigned)p.tiles_m, (unsigned)p.tiles_n, (unsigned)nets_of(p.nets));
+    if (p.patch == 8) hipLaunchKernelGGL(conv_stem_bf16_kernel, gs, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_stem_kernel, gs, dim3(256), 0, stream, p);
     D3F_HIP(hipGetLastError());
     return 0;
   }
@@ -877,13 +877,14 @@ int conv_patch_launch(const ConvParams& p, hipStream_t stream) {
                 p.tiles_n == (p.patch == 4 ? cdiv(p.Cout, 32) : 1) &&
                 (p.shift0 == 0) == (p.patch != 5),
             "conv: patch params were not planned");
-  if (p.patch == 7) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 32, false, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), dim3((unsigned)p.tiles_m, (unsigned)p.tiles_n), dim3(256), 0, stream, p);
-  else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), dim3((unsigned)p.tiles_m), dim3(256), 0, stream, p);
+  const dim3 g1((unsigned)p.tiles_m, 1, (unsigned)nets_of(p.nets)), g2((unsigned)p.tiles_m, (unsigned)p.tiles_n, (unsigned)nets_of(p.nets));
+  if (p.patch == 7) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 32, false, 16, true>), g1, dim3(256), 0, stream, p);
+  else if (p.patch == 6) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16, false, 8>), g1, dim3(256), 0, stream, p);
+  else if (p.patch == 5) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 16, true>), g1, dim3(256), 0, stream, p);
+  else if (p.patch == 4) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 32, 32>), g2, dim3(256), 0, stream, p);
+  else if (p.patch == 3) hipLaunchKernelGGL((conv_patch_kernel<bf16_t, 16, 16>), g1, dim3(256), 0, stream, p);
+  else if (p.C0 == 16) hipLaunchKernelGGL((conv_patch_kernel<float, 16, 16>), g1, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_patch_kernel<float, 4, 16>), g1, dim3(256), 0, stream, p);
   D3F_HIP(hipGetLastError());
   return 0;
 }

@@ -56,8 +56,9 @@ template <int C, int TW, int MW, int NW, int KW, int FM, bool S1 = false> struct
 };
 
 template <int C, int TW, int MW, int NW, int KW, int FM, bool S1 = false>
-__global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_pres_kernel(const ConvParams pin) {
   chain_priority();
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   using G = PresGeo<C, TW, MW, NW, KW, FM, S1>;
   constexpr int BM = G::BM, BN = G::BN, TR = G::TR, PC = G::PC, PIXD = G::PIXD, BROW = G::BROW, CV = G::CV;
   constexpr int CH = G::CH, NIT = G::NIT, NPV = G::NPV, NBV = G::NBV, LDC = G::LDC;
@@ -339,16 +340,13 @@ static PresPick pres_pick(const ConvParams& p) {
 
 bool conv_pres_applies(const ConvParams& p, int dtype) {
   if (pres_off() || dtype != D3F_BF16) return false;
-#ifdef D3F_NO_PATCH32  // A/B builds only: the round-4 bf16 plan
-  return false;
-#endif
   const bool mode_ok = p.mode == CONV_RAW_STATS || p.mode == CONV_EVAL_FUSED || (p.mode == CONV_DGRAD && p.out_c0 == p.Cout);
   if (!(mode_ok && p.par == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.C1 == 0 && p.shift0 == 0 &&
         p.zi == 0 && p.sum2 == 0 && p.Hv == p.Ho && p.Wv == p.Wo && p.Kpad == 9 * p.C0))
     return false;
   const PresPick k = pres_pick(p);
   if (!k.id || (p.Cout % k.BN) != 0 || (p.Ho % (k.BM / k.TW)) != 0) return false;
-  const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN);
+  const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN) * nets_of(p.plan_nets);
   // fewer workgroups: the implicit GEMM's split tiles fill the chip better (the 512-channel form holds 122 KB of LDS, one
   // workgroup per CU: 256 of them are one full round)
   // ... and many more (B = 64 eval batches: 2048): every workgroup streams the full weight matrix of its filter group, so the
@@ -372,7 +370,7 @@ int conv_pres_launch(const ConvParams& p, hipStream_t stream) {
   const PresPick k = pres_pick(p);
   D3F_CHECK(k.id && p.patch == 8 + k.id && p.tiles_m == p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) && p.tiles_n == p.Cout / k.BN,
             "conv: patch-resident params were not planned");
-  const dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n), block(256);
+  const dim3 grid((unsigned)p.tiles_m, (unsigned)p.tiles_n, (unsigned)nets_of(p.nets)), block(256);
   // data gradients: one weight stage (47 / 60 / 66 / 122 KB instead of 56 / 65 / 75 / 141): in the backward pass the launches
   // share the CUs with the weight-gradient stream's workgroups, and the LDS they leave free is co-residency
   // (same box: 3.388 / 3.389 / 3.407 -> 3.373 / 3.370 / 3.377 ms per bf16 step)

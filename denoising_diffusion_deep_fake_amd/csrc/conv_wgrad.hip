@@ -71,7 +71,8 @@ __device__ __forceinline__ void wg_split3x4(const uint4& v, uint2& h, uint2& m, 
 // source at (j + a - 1 + py, i + b - 1 + px) -- the low-resolution pixel under up-sampled row 2j + py + kh - 1 for the
 // taps kh that share `a` (kh = 0 | 1,2 for py = 0; kh = 0,1 | 2 for py = 1; columns alike).
 template <typename T, int BMW, int BNW, int WGM, int WGN, int KSPLIT, bool X3, bool CLS = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams pin) {
+  const WgradParams p = wgrad_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   constexpr int VE = Elem<T>::VE;
 
   static_assert(!X3 || (BMW == 64 && BNW == 64 && WGM == 2 && WGN == 2 && KSPLIT == 1), "x3 weight gradient: 64x64 tile");
@@ -88,10 +89,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int F32_FLOATS = (KP * (LY + LX) > RED) ? KP * (LY + LX) : RED;
   // bf16 storage: UB chunks of 32 pixels are staged per barrier pair (the matrix work of a chunk is two MFMAs -- with one
   // chunk per pair the loop was two barriers and a global-load latency per 2 MFMAs)
-#ifndef D3F_WGRAD_UB  // (A/B builds: -DD3F_WGRAD_UB=1 is the loop as before round 5)
-#define D3F_WGRAD_UB 2  // (same-box sweep: 1: 3.817, 2: 3.746, 4: 3.745, 8: 3.97 ms per bf16 step; 2 holds 16 KB of LDS, 4 holds 32)
-#endif
-  constexpr int UB = (X3 && sizeof(T) == 2) ? D3F_WGRAD_UB : 1;
+  // (same-box sweep of chunks per pair, round 5: 1: 3.817, 2: 3.746, 4: 3.745, 8: 3.97 ms per bf16 step; 2 holds 16 KB of LDS, 4 holds 32)
+  constexpr int UB = (X3 && sizeof(T) == 2) ? 2 : 1;
   constexpr int LDS_FLOATS = X3 ? UB * 2 * X3_OP / 4 : F32_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* Ys = lds;
@@ -493,11 +492,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedu
   const WgradReduceJob& q = tb.job[j];
   const int local = (int)blockIdx.x - q.block0;
   const int co = local % q.Cout, cz = local / q.Cout;
+  const float* partial = q.partial;
+  float* dw = q.dw;
+  if (blockIdx.y != 0) {  // two networks in one launch (common.h, NetSplit): blockIdx.y = net
+    net_shift(partial, tb.net_ws);
+    net_shift(dw, tb.net_grad);
+  }
   if (q.fold)
-    wgrad_reduce_body<true>(row, q.partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, q.dw, q.CinTot,
+    wgrad_reduce_body<true>(row, partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, dw, q.CinTot,
                             q.c_off, co, cz * q.CB);
   else
-    wgrad_reduce_body<false>(row, q.partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, q.dw, q.CinTot,
+    wgrad_reduce_body<false>(row, partial, q.splits, q.CoutP, q.Cin, q.CinReal, q.taps, q.CB, q.nsg, q.VB, dw, q.CinTot,
                              q.c_off, co, cz * q.CB);
 }
 
@@ -577,7 +582,8 @@ int wgrad_plan(WgradParams& p, int dtype) {
   // fp32: ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %).  bf16 storage
   // (round 5 sweep, profiles/README.md: 232 ... 1856): the launches are latency-bound, not MFMA-bound, and the stream is as
   // long as the chain in the backward window -- 1152 is 1.2 % faster per step than 928, 640 1.4 % slower, 1856 1.8 % slower
-  const long target = target_env > 0 ? target_env : (dtype == D3F_BF16 ? 1152 : 928);
+  // (two networks in one launch share the target: half the slabs per net)
+  const long target = (target_env > 0 ? target_env : (dtype == D3F_BF16 ? 1152 : 928)) / nets_of(p.plan_nets);
   long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;
@@ -622,7 +628,7 @@ int wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
   const int t = pick_wtile(p);
   D3F_CHECK(p.tiles_co == cdiv(p.Cout, t) && p.splits >= 1 && p.slab_taps >= 1 && p.Mi >= 1, "wgrad: params were not planned");
   D3F_CHECK(!p.cls || t == 64, "wgrad: class form needs the 64x64 tile");
-  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits);
+  const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co * p.slab_taps), (unsigned)p.splits, (unsigned)nets_of(p.nets));
   const bool prof = prof_enabled(PROF_WGRAD);
   if (prof) prof_begin(PROF_WGRAD, p.flops, stream);
   if (dtype == D3F_BF16) wgrad_launch_t<bf16_t>(p, t, grid, stream, false);
@@ -670,7 +676,7 @@ int wgrad_reduce_batch_add(WgradReduceBatch& tb, const float* partial, int split
 
 int wgrad_reduce_batch_launch(const WgradReduceBatch& tb, hipStream_t stream) {
   if (tb.n == 0) return 0;
-  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)tb.blocks), dim3(256), (size_t)tb.lds, stream, tb);
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)tb.blocks, (unsigned)nets_of(tb.nets)), dim3(256), (size_t)tb.lds, stream, tb);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -705,10 +711,17 @@ size_t wgrad_layer_partial_floats(const WgradLayer& L) {
 // and its reduce is appended to `tb` for a later wgrad_reduce_batch_launch on the same stream
 int wgrad_layer_launch_deferred(const WgradLayer& L, const void* dy, const void* src0, const void* src1, float* partial,
                                 float* dw, int CoutReal, int CinReal, int dtype, WgradReduceBatch& tb,
-                                hipStream_t stream) {
+                                hipStream_t stream, const NetSplit* ns) {
+  if (ns != nullptr && ns->nets > 1) {  // two networks: every launch and the reduce carry both (common.h, NetSplit)
+    tb.nets = ns->nets;
+    tb.net_ws = ns->ws;
+    tb.net_grad = ns->grad;
+  }
   for (int i = 0; i < L.nparts; ++i) {
     WgradParams w = L.part[i];
     w.dy = dy; w.src0 = src0; w.src1 = src1; w.partial = partial;
+    w.nets = ns != nullptr ? ns->nets : 1;
+    w.net_ws = ns != nullptr ? ns->ws : 0;
     if (int rc = wgrad_launch(w, dtype, stream)) return rc;
     const int c_off = w.ci_base;
     const int creal = std::max(0, std::min(w.slab_cin, CinReal - c_off));

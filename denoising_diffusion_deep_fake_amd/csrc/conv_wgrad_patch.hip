@@ -48,7 +48,8 @@ template <> __device__ __forceinline__ void patch_store_f32<bf16_t>(float* dst, 
 // 3 are the image's; with CR = 3 the 49 taps are 147 columns = 5 column tiles instead of 196 -> 7 (a quarter of the MFMAs
 // computed the gradient of the zero pad channel); the pad channels' slab entries are written as zeros.
 template <typename T, int MT, int CI_T, int KS, int S, int TW, int CR = CI_T>
-__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams pin) {
+  const WgradParams p = wgrad_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   constexpr int VE = Elem<T>::VE;
   constexpr int CO_T = MT;
   // HALFV (the stem in bf16 storage: 3 image channels padded to one 16-byte vector of 8): only the first CI_T = 4
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_kernel(const WgradParams
 // of a slab write disjoint taps; wgrad_reduce_kernel<true> folds them into the 3x3 gradient.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int MT, int CI_T, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradParams pin) {
+  const WgradParams p = wgrad_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   constexpr int VE = Elem<T>::VE;
   constexpr int CO_T = MT;
   constexpr int RH = PT_TH / 2;                   // tile rows of one parity: one per wave
@@ -397,7 +399,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_cls_kernel(const WgradPa
 // x >> 1) while staging, so the class-form kernels are not needed: the 9 taps are 9 cheap MFMAs).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PB_TW = 16;
-__global__ __launch_bounds__(256) void conv_wgrad_patch_bf16_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void conv_wgrad_patch_bf16_kernel(const WgradParams pin) {
+  const WgradParams p = wgrad_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   typedef short v4s __attribute__((ext_vector_type(4)));
   constexpr int TW = PB_TW, KS = 3, PH = PT_TH + 2, PW = TW + 2;
   constexpr int XB = PH * PW * 64, YB = PT_TH * TW * 64;   // bytes
@@ -523,7 +526,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_patch_bf16_kernel(const WgradP
 int wgrad_patch_variant(const WgradParams& p, int dtype) {
   const int cin = p.C0 + p.C1;
   if (p.KH != p.KW) return 0;
-#ifndef D3F_NO_WGRAD_PATCH_BF16  // (A/B builds: -DD3F_NO_WGRAD_PATCH_BF16 keeps the widened-to-fp32 kernels)
   // bf16 storage: every narrow 3x3 stride-1 layer on the native bf16 kernel (7), whole layers only (no class form)
   // ... up to 128 filters and 384 input channels (layer1, layer2, decoder blocks 1-4): a workgroup owns one (32 filters x 32
   // channels) pair, so dY / X are read Cin/32 / Cout/32 times instead of the tap-parallel kernel's 9; round-5 sweep of the
@@ -534,7 +536,6 @@ int wgrad_patch_variant(const WgradParams& p, int dtype) {
   if (dtype == D3F_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Cout <= maxco && (cin == 16 || (cin % 32 == 0 && cin <= maxci)) &&
       (p.C1 == 0 || p.C0 % 32 == 0) && (p.C0 % 8) == 0 && (p.C1 % 8) == 0 && (p.Cout % 8) == 0)
     return 7;
-#endif
   if (p.KH == 3 && p.stride == 1 && p.pad == 1) {
     if (p.Cout <= 16 && cin % 32 == 0 && cin <= 64 && (p.C1 == 0 || p.C0 % 32 == 0)) return 1;
     if (p.Cout <= 16 && cin == 16) return 2;
@@ -562,7 +563,7 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   // the fp32-MFMA kernels: 2 per CU (round 5 sweep 384 / 448 / 512 / 576 / 640 / 768 / 1024 workgroups: 7.85 / 7.81 / 7.80 /
   // 7.94 / 7.91 / 7.875 / 7.91 ms per fp32 step; rounds 1-4 ran 768)
   static const int gall = getenv("D3F_WGRAD_PATCH_WGS") ? atoi(getenv("D3F_WGRAD_PATCH_WGS")) : 512;  // sweep knob
-  int g = (variant == 7 ? g7 : gall) / slices;
+  int g = (variant == 7 ? g7 : gall) / nets_of(p.plan_nets) / slices;  // (two networks in one launch share the count)
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   *gx = g;
@@ -584,7 +585,7 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
   int gx, gy;
   wgrad_patch_grid(p, variant, &gx, &gy);
   D3F_CHECK(p.splits == gx, "wgrad patch: params were not planned (splits %d vs %d)", p.splits, gx);
-  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nets_of(p.nets)), block(256);
   if (p.cls) {
     D3F_CHECK((variant == 1 || variant == 3) && p.slab_cin == p.C0 && (p.C0 % 32) == 0 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0,
               "wgrad patch: class form needs variant 1 or 3 and whole 32-channel slices of source 0");

@@ -48,7 +48,7 @@ bool conv_winograd_fits(const ConvParams& p, int dtype) {
 bool conv_winograd_applies(const ConvParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_WINOGRAD") != nullptr;  // debugging knob: the implicit GEMM instead
   if (off || !conv_winograd_fits(p, dtype)) return false;
-  const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64);
+  const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64) * nets_of(p.plan_nets);
   // one workgroup per CU or more, and few enough chunks that the fixed cost per workgroup is what the tile form pays for
   // (128 channels on 128 workgroups: 44.9 us against the implicit GEMM's 45)
   return wgs >= 256;
@@ -91,8 +91,9 @@ int conv_winograd_pack_launch(const float* w, float* u, int K, int C, hipStream_
 }
 
 // p.src0 [B][H][W][C] fp32, p.w = U (above), p.out0 = y [B][H][W][K] fp32, p.stats [workgroup rows][CoutPad][2] or null
-__global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_winograd_kernel(const ConvParams pin) {
   chain_priority();
+  const ConvParams p = conv_params_of_net(pin, (int)blockIdx.z);  // two networks in one launch: blockIdx.z = net
   __shared__ __attribute__((aligned(16))) float P[WPP * WPP * WCK];
   __shared__ __attribute__((aligned(16))) float V[2][16 * 64 * WCK];
   const int H = p.Hv, W = p.Wv, C = p.C0, K = p.Cout;
@@ -304,7 +305,7 @@ int conv_winograd_launch(const ConvParams& p, hipStream_t stream) {
   ConvParams q = p;
   q.src0_bytes = (unsigned)((size_t)p.B * p.Hv * p.Wv * p.C0 * 4);
   q.w_bytes = (unsigned)((size_t)16 * p.C0 * p.Cout * 4);
-  const dim3 grid((unsigned)(p.B * (p.Hv / 16) * (p.Wv / 16)), (unsigned)(p.Cout / 64));
+  const dim3 grid((unsigned)(p.B * (p.Hv / 16) * (p.Wv / 16)), (unsigned)(p.Cout / 64), (unsigned)nets_of(p.nets));
   const bool prof = prof_enabled(PROF_CONV_FWD);
   if (prof) prof_begin(PROF_CONV_FWD, q.flops, stream);  // the algorithmic (direct) FLOP count of the layer
   hipLaunchKernelGGL(conv_winograd_kernel, grid, dim3(256), 0, stream, q);

@@ -87,21 +87,33 @@ struct BwdOp {
   int segment = 0;
 };
 
+// Two networks in one engine (common.h, NetSplit): the caller-owned buffers of the second network as byte offsets from
+// the first one's (parameters, running statistics, gradients, NCHW input, NCHW prediction, NCHW output gradient).  The
+// workspace of a pair is ONE buffer of UnetEngine::workspace_bytes: two copies of the single-network layout,
+// net_ws_stride bytes apart.
+struct NetIO {
+  long params = 0, bnstats = 0, grads = 0, x = 0, out = 0, dout = 0;
+};
+
 class UnetEngine {
  public:
   ~UnetEngine();
-  int build(const char* encoder, int in_channels, int classes, int B, int H, int W, int dtype);
+  // nets: 1, or 2 = train_deep_fake's denoise-mode pair (model_a / model_b, d3f/train_deep_fake/lit_module.py:142-181) as
+  // ONE set of launches; plan_nets (>= nets): the tile / split / patch-kernel choices count the workgroups of plan_nets
+  // networks -- a single engine built with plan_nets = 2 runs exactly the kernels of the pair, net by net
+  int build(const char* encoder, int in_channels, int classes, int B, int H, int W, int dtype, int nets = 1,
+            int plan_nets = 1);
 
-  int pack_weights(const float* params, void* ws, hipStream_t s) const;
+  int pack_weights(const float* params, void* ws, hipStream_t s, const NetIO* io = nullptr) const;
   int forward(const float* params, float* bnstats, const float* x, float* out, void* ws, int training,
-              hipStream_t s) const;
+              hipStream_t s, const NetIO* io = nullptr) const;
   // join != 0: every gradient of the segments is final on `s` when the call returns.  join == 0 (data-parallel
   // callers): nothing makes `s` wait -- the segments' gradients are final on side_stream() once everything this call
   // enqueued there has run (the side stream also waits for the caller's stream at the end of each segment, so an
   // event recorded on it covers the BatchNorm / bias gradients written on the caller's stream too); backward_join()
   // later makes a stream wait for all of it.
   int backward(const float* params, const float* dout, float* grads, void* ws, int seg_begin,
-               int seg_end, hipStream_t s, int join = 1) const;
+               int seg_end, hipStream_t s, int join = 1, const NetIO* io = nullptr) const;
   int backward_join(hipStream_t s) const;
   hipStream_t side_stream() const;  // creates the engine's streams on first use; nullptr in D3F_SERIAL_BACKWARD mode
   // eval-mode forward on uint8 BGR frames with the K16 pre/post kernels fused in (in_channels = classes = 3);
@@ -141,6 +153,8 @@ class UnetEngine {
   int num_segments = 4;
   long seg_grad_begin[8] = {0}, seg_grad_end[8] = {0};
   int B = 0, H = 0, W = 0, dtype = 0, in_channels = 3, classes = 3;
+  int nets = 1, plan_nets = 1;     // B = images PER network
+  size_t net_ws_stride = 0;        // bytes between the two networks' workspace copies (0 for a single network)
   int cdtype = 0;  // contraction dtype handed to the conv kernels (dtype = storage dtype; differs for D3F_F32X3)
   double fwd_flops = 0, bwd_flops = 0;  // algorithmic conv FLOPs (2*MAC) per call
   std::vector<Unit> units;
@@ -184,7 +198,16 @@ class UnetEngine {
   int first_mid_unit_ = -1;   // first unit (index into `units`) of the second part (encoder.layer1)
   int first_late_unit_ = -1;  // first unit of the third part (encoder.layer3)
   // predict_u8 graph: private capture/launch stream + the pointers and constants the captured graph bakes in
-  int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s) const;
+  int forward_body(const float* params, float* bnstats, float* out, char* ws, int training, hipStream_t s,
+                   const NetSplit* ns = nullptr) const;
+  // what a launch of this engine hands to the kernels: null for a single network
+  bool make_split(const NetIO* io, long in_delta, NetSplit* ns) const;
+  static void net_conv(ConvParams& p, const NetSplit* ns) {
+    if (ns != nullptr) {
+      p.nets = ns->nets;
+      p.net_ws = p.net_out0 = p.net_scale = ns->ws;
+    }
+  }
   int predict_u8_launches(const float* params, float* bnstats, const uint8_t* bgr_in, uint8_t* bgr_out,
                           const float mean255[3], const float std255[3], char* ws, hipStream_t s) const;
   // captured graphs: one slot per entry point; a slot is re-captured when the pointers / constants it baked in change
@@ -215,6 +238,6 @@ class UnetEngine {
 };
 
 int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
-                            hipStream_t stream);
+                            hipStream_t stream, const NetSplit* ns = nullptr);
 
 }  // namespace d3f

@@ -21,9 +21,14 @@ namespace d3f {
 // 16-byte loads; partial[c][b * CS_PP + segment], summed in that order by the final kernel (fixed order: reproducible)
 constexpr int CS_PP = 16;
 __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int C, long HW,
-                                                                  float* __restrict__ partial) {
+                                                                  float* __restrict__ partial, int nb, long net_in,
+                                                                  long net_ws) {
   __shared__ float red[256];
-  const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
+  // two networks in one launch (common.h, NetSplit): blockIdx.z = net * nb + image
+  const int seg = blockIdx.x, c = blockIdx.y, b = (int)blockIdx.z % nb;
+  if ((int)blockIdx.z >= nb) {
+    net_shift(x, net_in); net_shift(partial, net_ws);
+  }
   const float* __restrict__ plane = x + ((long)b * C + c) * HW;
   const long per = (HW + CS_PP - 1) / CS_PP, lo = (long)seg * per, hi = lo + per < HW ? lo + per : HW;
   float s = 0.f;
@@ -44,7 +49,10 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
   if (threadIdx.x == 0) partial[((long)c * nb + b) * CS_PP + seg] = red[0];
 }
 __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int C, int n,
-                                         float* __restrict__ out) {
+                                         float* __restrict__ out, long net_ws, long net_grad) {
+  if (blockIdx.z != 0) {  // two networks in one launch: the head's bias gradient lands in net 1's flat gradient
+    net_shift(partial, net_ws); net_shift(out, net_grad);
+  }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
@@ -53,11 +61,14 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 }
 size_t channel_sum_partial_floats(int B, int C) { return (size_t)B * C * CS_PP; }
 int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
-                            hipStream_t stream) {
-  D3F_CHECK(B <= 65535 && C <= 65535, "channel sum: grid (%d, %d)", C, B);
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PP, C, B), dim3(256), 0, stream, x, C, HW, partial);
+                            hipStream_t stream, const NetSplit* ns) {
+  const NetSplit nv = net_split_or_single(ns);
+  D3F_CHECK(B * nv.nets <= 65535 && C <= 65535, "channel sum: grid (%d, %d)", C, B);
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PP, C, B * nv.nets), dim3(256), 0, stream, x, C, HW, partial, B,
+                     nv.in, nv.ws);
   D3F_HIP(hipGetLastError());
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, partial, C, B * CS_PP, out);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64), 1, nv.nets), dim3(64), 0, stream, partial, C, B * CS_PP, out,
+                     nv.ws, nv.grad);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -172,6 +183,7 @@ int UnetEngine::plan_unit(Unit& u) {
   f.KH = u.KH; f.KW = u.KW; f.stride = u.stride; f.pad = u.pad;
   f.M = B * u.Ho * u.Wo;
   f.mode = u.bn ? CONV_RAW_STATS : CONV_HEAD_NCHW;
+  f.plan_nets = plan_nets;
   const long rows_full = (long)B * u.Ho * u.Wo;
   if (u.upfold) {  // rows = one output-parity class; src0 described at its own (low) resolution
     f.par = 3;
@@ -209,6 +221,7 @@ int UnetEngine::plan_unit(Unit& u) {
   g.KH = u.KH; g.KW = u.KW; g.stride = u.stride; g.pad = u.pad; g.M = (int)rows_full;
   g.cin_real = u.CinReal;
   g.flops = 2.0 * macs;
+  g.plan_nets = plan_nets;
   if (int rc = wgrad_layer_plan(u.wl, g, dtype)) return rc;
   u.wclass = u.wl.part[0].part != WG_WHOLE;
   u.wslab_off = alloc(wgrad_layer_partial_floats(u.wl) * sizeof(float));
@@ -226,6 +239,7 @@ int UnetEngine::plan_unit(Unit& u) {
     l.M = B * l.Ho * l.Wo;
     l.mode = CONV_DGRAD;
     l.out_c0 = u.C0;
+    l.plan_nets = plan_nets;
     if (int rc = conv_igemm_plan(l, cdtype, true)) return rc;
     if (conv_splitk_floats(l) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(l) * sizeof(float);
     l.flops = 2.0 * macs * u.C0 / u.Cin();
@@ -240,6 +254,7 @@ int UnetEngine::plan_unit(Unit& u) {
       d.M = (int)rows_full;
       d.mode = CONV_DGRAD;
       d.out_c0 = u.C1;
+      d.plan_nets = plan_nets;
       if (int rc = conv_igemm_plan(d, cdtype, true)) return rc;
       if (conv_splitk_floats(d) * sizeof(float) > splitk_bytes) splitk_bytes = conv_splitk_floats(d) * sizeof(float);
       d.flops = 2.0 * macs * u.C1 / u.Cin();
@@ -254,6 +269,7 @@ int UnetEngine::plan_unit(Unit& u) {
     d.B = B; d.C0 = u.CoutD; d.C1 = 0;
     d.Cout = u.Cin(); d.CoutPad = u.CinRows; d.Kpad = u.KpadD;
     d.mode = CONV_DGRAD;
+    d.plan_nets = plan_nets;
     d.out_c0 = u.C1 > 0 ? u.C0 : u.Cin();
     if (parity_dgrad_applies(dtype, u.stride, u.KH, u.pad, u.CoutD, u.C1)) {
       // stride 2: four plain sub-convolutions over dY, one per output-parity class (conv_igemm.hip)
@@ -285,8 +301,12 @@ int UnetEngine::plan_unit(Unit& u) {
 }
 
 int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B_, int H_, int W_,
-                      int dtype_) {
+                      int dtype_, int nets_, int plan_nets_) {
   D3F_CHECK(dtype_ == D3F_F32 || dtype_ == D3F_BF16 || dtype_ == D3F_F32X3, "unet: dtype %d", dtype_);
+  D3F_CHECK((nets_ == 1 || nets_ == 2) && (plan_nets_ == 1 || plan_nets_ == 2) && plan_nets_ >= nets_,
+            "unet: nets=%d, plan_nets=%d (one network, or the pair of train_deep_fake's denoise mode)", nets_, plan_nets_);
+  nets = nets_;
+  plan_nets = plan_nets_;
   D3F_CHECK(B_ >= 1 && H_ >= 32 && W_ >= 32, "unet: bad shape B=%d H=%d W=%d", B_, H_, W_);
   D3F_CHECK(H_ % 32 == 0 && W_ % 32 == 0,
             "Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.",
@@ -473,7 +493,9 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   bsum_off = alloc(channel_sum_partial_floats(B, classes) * sizeof(float));
   splitk_off = alloc(splitk_bytes);
   head_nchw_off = alloc((size_t)B * classes * H * W * sizeof(float));  // predict_u8: head output before K16 post
-  workspace_bytes = ws_top;
+  // a pair keeps two copies of this layout in one buffer, a whole number of 4 KB pages apart
+  net_ws_stride = nets > 1 ? (size_t)round_up((long)ws_top, 4096) : 0;
+  workspace_bytes = nets > 1 ? net_ws_stride * nets : ws_top;
 
   // ---- gradient buckets (contiguous slices of the flat gradient, ready in this order) ----
   long layer3_start = -1, layer4_start = -1, dec_start = -1;
@@ -540,13 +562,28 @@ int UnetEngine::ensure_streams() const {
   return 0;
 }
 
-int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) const {
+bool UnetEngine::make_split(const NetIO* io, long in_delta, NetSplit* ns) const {
+  if (nets <= 1) return false;
+  ns->nets = nets;
+  ns->ws = (long)net_ws_stride;
+  ns->par = io->params;
+  ns->grad = io->grads;
+  ns->bn = io->bnstats;
+  ns->in = in_delta;
+  ns->out = io->out;
+  return true;
+}
+
+int UnetEngine::pack_weights(const float* params0_, void* ws0_, hipStream_t s, const NetIO* io) const {
   D3F_CHECK((int)units.size() <= PACK_MAX_LAYERS, "pack_weights: %d layers exceed the table", (int)units.size());
+  D3F_CHECK(nets == 1 || io != nullptr, "pack_weights: a pair engine needs the second network's offsets");
   const int ve = dtype == D3F_F32 ? 4 : 8;
   static const bool sync_pack = getenv("D3F_NO_ASYNC_PACK") != nullptr;  // debugging knob: everything on the caller's stream
   const bool async = !sync_pack && first_late_unit_ > 0;
-  char* ws = reinterpret_cast<char*>(ws_);
   const int mid = async ? first_mid_unit_ : -1;
+  // (a pair: every layout launch once per network -- these are HBM-bound, chip-filling launches off the critical path)
+  auto params_of = [&](int n) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(params0_) + (n ? io->params : 0)); };
+  auto ws_of = [&](int n) { return reinterpret_cast<char*>(ws0_) + (size_t)n * net_ws_stride; };
   // parts: 0 = the first layers (caller's stream: encoder.conv1, or everything before layer3 without a middle part),
   // 1 = layer1-2 (side stream, own event; empty without a middle part), 2 = the rest (side stream)
   auto part_of = [&](int ui) { return ui >= first_late_unit_ ? 2 : (mid > 0 && ui >= mid) ? 1 : 0; };
@@ -604,27 +641,35 @@ int UnetEngine::pack_weights(const float* params_, void* ws_, hipStream_t s) con
       }
       ps = side_;
     }
-    if (t.n > 0)
-      if (int rc = pack_all_launch(cdtype, params_, ws_, t, (int)blocks, ps)) return rc;
-    // transformed filters of the Winograd layers of this part, behind its plain layouts
-    for (int ui = 0; ui < (int)units.size(); ++ui) {
+    for (int n = 0; n < nets; ++n) {
+      const float* params_ = params_of(n);
+      char* ws = ws_of(n);
+      if (t.n > 0)
+        if (int rc = pack_all_launch(cdtype, params_, ws, t, (int)blocks, ps)) return rc;
+      // transformed filters of the Winograd layers of this part, behind its plain layouts
+      for (int ui = 0; ui < (int)units.size(); ++ui) {
         const Unit& u = units[ui];
         if (!u.wino) continue;
         if (first_late_unit_ > 0 ? part_of(ui) != part : part != 0) continue;
         if (int rc = conv_winograd_pack_launch(params_ + u.w_off, reinterpret_cast<float*>(ws + u.wu_off), u.Cout, u.Cin(), ps))
           return rc;
       }
+    }
     if (part == 1 && async) {
       D3F_HIP(hipEventRecord(ev_pack_mid_, side_));
       pack_mid_pending_ = true;
     }
     if (part == 2 || (first_late_unit_ <= 0 && part == 0)) {
-      for (const Unit& u : units)  // the folded decoder layers: all late
-        if (u.upfold)
-          if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
-                                      u.need_dgrad ? ws + u.wd4_off : nullptr, u.C0Rows,
-                                      (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, ps))
-            return rc;
+      for (int n = 0; n < nets; ++n) {
+        const float* params_ = params_of(n);
+        char* ws = ws_of(n);
+        for (const Unit& u : units)  // the folded decoder layers: all late
+          if (u.upfold)
+            if (int rc = pack_up_launch(cdtype, params_ + u.w_off, u.Cout, u.C0, u.C1, ws + u.wfc_off, u.CoutPad,
+                                        u.need_dgrad ? ws + u.wd4_off : nullptr, u.C0Rows,
+                                        (u.need_dgrad && u.C1 > 0) ? ws + u.wds_off : nullptr, u.C1Rows, ps))
+              return rc;
+      }
     }
     if (part == 2 && async) {
       D3F_HIP(hipEventRecord(ev_pack_done_, side_));
@@ -639,17 +684,23 @@ static inline float* coef_ptr(char* ws, const Unit& u, int which) {
 }
 
 int UnetEngine::forward(const float* params_, float* bnstats, const float* x, float* out, void* ws_,
-                        int training, hipStream_t s) const {
+                        int training, hipStream_t s, const NetIO* io) const {
   char* ws = reinterpret_cast<char*>(ws_);
-  if (int rc = nchw_to_nhwc_launch(dtype, x, ws + tensors[t_x].off, B, in_channels, H, W, tensors[t_x].C, s))
+  D3F_CHECK(nets == 1 || (io != nullptr && training), "unet: the pair engine runs train-mode passes and needs the second "
+            "network's offsets");
+  NetSplit split{};
+  const NetSplit* ns = make_split(io, io ? io->x : 0, &split) ? &split : nullptr;
+  if (int rc = nchw_to_nhwc_launch(dtype, x, ws + tensors[t_x].off, B, in_channels, H, W, tensors[t_x].C, s, ns))
     return rc;
-  return forward_body(params_, bnstats, out, ws, training, s);
+  return forward_body(params_, bnstats, out, ws, training, s, ns);
 }
 
 // everything after the input layout conversion; `out` = NCHW fp32 destination of the head
 int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, char* ws, int training,
-                             hipStream_t s) const {
+                             hipStream_t s, const NetSplit* ns) const {
   auto T = [&](int tid) { return ws + tensors[tid].off; };
+  D3F_CHECK(ns == nullptr || (training && bn_sync_fn_ == nullptr), "unet: the pair engine runs train-mode passes with "
+            "per-GPU BatchNorm statistics");
   if (!training) {  // folded BatchNorm coefficients of all layers: one launch
     BnEvalTable t;
     t.n = 0;
@@ -669,7 +720,7 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
       const TensorD& f1 = tensors[units[conv1].a];
       if (int rc = maxpool3x3s2_fwd_launch(dtype, T(units[conv1].a), T(t_pool),
                                            reinterpret_cast<uint8_t*>(ws + pool_idx_off), B, f1.H, f1.W,
-                                           f1.C, s))
+                                           f1.C, s, ns))
         return rc;
       continue;
     }
@@ -686,10 +737,15 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
     p.src0 = T(u.in0);
     p.src1 = u.in1 >= 0 ? T(u.in1) : nullptr;
     p.w = ws + (u.upfold ? u.wfc_off : u.wf_off);
+    net_conv(p, ns);
     if (!u.bn) {  // segmentation head
       p.mode = CONV_HEAD_NCHW;
       p.out0 = out;
       p.scale = params_ + u.bias_off;
+      if (ns != nullptr) {  // the prediction and the bias live outside the workspace
+        p.net_out0 = ns->out;
+        p.net_scale = ns->par;
+      }
       if (int rc = conv_igemm_launch(p, cdtype, s)) return rc;
       continue;
     }
@@ -721,21 +777,21 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
                                               coef_ptr(ws, u, 3), T(u.y),
                                               u.res_tensor >= 0 ? T(u.res_tensor) : nullptr, ds ? T(ds->y) : nullptr,
                                               ds ? coef_ptr(ws, *ds, 2) : nullptr, ds ? coef_ptr(ws, *ds, 3) : nullptr,
-                                              u.relu ? 1 : 0, T(u.a), rows, s))
+                                              u.relu ? 1 : 0, T(u.a), rows, s, ns, plan_nets))
           return rc;
         continue;
       }
       if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, count,
                                       params_ + u.g_off, params_ + u.b_off, 1e-5f, 0.1f,
                                       bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
-                                      coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s))
+                                      coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s, ns))
         return rc;
       if (u.apply) {
         if (int rc = bn_apply_launch(dtype, T(u.y), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3),
                                      u.res_tensor >= 0 ? T(u.res_tensor) : nullptr,
                                      ds ? T(ds->y) : nullptr, ds ? coef_ptr(ws, *ds, 2) : nullptr,
                                      ds ? coef_ptr(ws, *ds, 3) : nullptr, u.relu ? 1 : 0, T(u.a),
-                                     rows, u.Cout, s))
+                                     rows, u.Cout, s, ns))
           return rc;
       }
     } else {
@@ -947,8 +1003,12 @@ int UnetEngine::backward_join(hipStream_t s) const {
 }
 
 int UnetEngine::backward(const float* params_, const float* dout, float* grads, void* ws_,
-                         int seg_begin, int seg_end, hipStream_t s, int join) const {
+                         int seg_begin, int seg_end, hipStream_t s, int join, const NetIO* io) const {
   char* ws = reinterpret_cast<char*>(ws_);
+  D3F_CHECK(nets == 1 || (io != nullptr && bn_sync_fn_ == nullptr), "unet: the pair engine needs the second network's "
+            "offsets and runs with per-GPU BatchNorm statistics");
+  NetSplit split{};
+  const NetSplit* ns = make_split(io, io ? io->dout : 0, &split) ? &split : nullptr;
   auto T = [&](int tid) { return ws + tensors[tid].off; };
   auto G = [&](int gid) { return gid == -2 ? ws + dz_off : ws + gtensors[gid].off; };
   const bool serial = serial_backward();
@@ -993,7 +1053,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     if (head_bias_pending) {  // the head's bias gradient: two small launches that nothing on the chain waits for
       const Unit& uh = units[head];
       if (int rc = channel_sum_nchw_launch(dout, B, uh.Cout, (long)uh.Ho * uh.Wo, reinterpret_cast<float*>(ws + bsum_off),
-                                           grads + uh.bias_off, ws_stream))
+                                           grads + uh.bias_off, ws_stream, ns))
         return rc;
       head_bias_pending = false;
     }
@@ -1002,7 +1062,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       WgradReduceBatch red;
       if (int rc = wgrad_layer_launch_deferred(u.wl, ws + u.dy_off, T(u.in0), u.in1 >= 0 ? T(u.in1) : nullptr,
                                                reinterpret_cast<float*>(ws + u.wslab_off), grads + u.w_off, u.Cout,
-                                               u.CinReal, cdtype, red, ws_stream))
+                                               u.CinReal, cdtype, red, ws_stream, ns))
         return rc;
       if (!skip_r)
         if (int rc = wgrad_reduce_batch_launch(red, ws_stream)) return rc;
@@ -1017,13 +1077,13 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       pending_segment = op.segment;
     }
     if (op.kind == BW_SUM2X2) {
-      if (int rc = sum2x2_launch(dtype, ws + dfull_off, G(op.dst0), B, op.Hl, op.Wl, op.C, s)) return rc;
+      if (int rc = sum2x2_launch(dtype, ws + dfull_off, G(op.dst0), B, op.Hl, op.Wl, op.C, s, ns)) return rc;
       continue;
     }
     if (op.kind == BW_POOL) {
       const TensorD& f1 = tensors[units[conv1].a];
       if (int rc = maxpool3x3s2_bwd_launch(dtype, G(op.dA), reinterpret_cast<uint8_t*>(ws + pool_idx_off),
-                                           G(op.dst0), op.acc0 ? 1 : 0, B, f1.H, f1.W, f1.C, s))
+                                           G(op.dst0), op.acc0 ? 1 : 0, B, f1.H, f1.W, f1.C, s, ns))
         return rc;
       continue;
     }
@@ -1031,10 +1091,10 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
     const long rows = (long)B * u.Ho * u.Wo;
     char* dy = ws + u.dy_off;
     if (op.kind == BW_HEAD) {
-      if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s)) return rc;
+      if (int rc = nchw_to_nhwc_launch(dtype, dout, dy, B, u.Cout, u.Ho, u.Wo, u.CoutD, s, ns)) return rc;
       if (skip_w) {  // (profiling ablation without weight-gradient launches: nothing would flush it)
         if (int rc = channel_sum_nchw_launch(dout, B, u.Cout, (long)u.Ho * u.Wo,
-                                             reinterpret_cast<float*>(ws + bsum_off), grads + u.bias_off, s))
+                                             reinterpret_cast<float*>(ws + bsum_off), grads + u.bias_off, s, ns))
           return rc;
       } else {
         head_bias_pending = true;  // with the head's weight gradient, on the weight-gradient stream (flush_pending)
@@ -1057,7 +1117,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       } else if (op.fused_rows > 0) {
         nb = op.fused_rows;  // the producing data gradient already left the partial sums in bnpart
       } else if (int rc = bn_bwd_reduce_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, bnpart, &nb, rows,
-                                               u.Cout, s, msc, msf)) {
+                                               u.Cout, s, msc, msf, ns)) {
         return rc;
       }
       const bool sync = bn_sync_fn_ != nullptr && !skip_b;
@@ -1081,15 +1141,15 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         if (int rc = bn_bwd_finalize_apply_launch(dtype, bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,
                                                   grads + u.g_off, grads + u.b_off, 0, k, G(op.dA), amask, T(u.y), dy,
                                                   op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows, s,
-                                                  msc, msf))
+                                                  msc, msf, ns, plan_nets))
           return rc;
       } else if (!skip_b) {
         if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd,
-                                            grads + u.g_off, grads + u.b_off, 0, k, s))
+                                            grads + u.g_off, grads + u.b_off, 0, k, s, ns))
           return rc;
         if (int rc = bn_bwd_apply_launch(dtype, G(op.dA), amask, T(u.y), mean, invstd, k, dy,
                                          op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
-                                         u.Cout, s, msc, msf))
+                                         u.Cout, s, msc, msf, ns))
           return rc;
       }
     }
@@ -1110,6 +1170,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       l.out0 = G(op.dst0);
       l.acc0 = op.acc0 ? 1 : 0;
       l.partial = l.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+      net_conv(l, ns);
       if (op.fuse_for_unit >= 0) {
         const Unit& uc = units[op.fuse_for_unit];
         l.bn_y = T(uc.y);
@@ -1127,6 +1188,7 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
         d.out0 = G(op.dst1);
         d.acc0 = op.acc1 ? 1 : 0;
         d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+        net_conv(d, ns);
         if (int rc = conv_igemm_launch(d, cdtype, s)) return rc;
       }
     } else if (u.need_dgrad && !skip_d) {
@@ -1143,8 +1205,11 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
       d.out1 = op.dst1 >= 0 ? G(op.dst1) : nullptr;
       d.acc1 = op.acc1 ? 1 : 0;
       d.partial = d.splitk > 1 ? reinterpret_cast<float*>(ws + splitk_off) : nullptr;
+      net_conv(d, ns);
       if (d.par == 2 && !d.acc0)  // 1x1 stride 2: only even pixels receive a gradient; the others are zero
-        D3F_HIP(hipMemsetAsync(d.out0, 0, (size_t)4 * d.M * d.Cout * esize(), s));
+        for (int n = 0; n < nets; ++n)
+          D3F_HIP(hipMemsetAsync(reinterpret_cast<char*>(d.out0) + (size_t)n * net_ws_stride, 0,
+                                 (size_t)4 * d.M * d.Cout * esize(), s));
       if (op.fuse_for_unit >= 0) {
         const Unit& uc = units[op.fuse_for_unit];
         d.bn_y = T(uc.y);

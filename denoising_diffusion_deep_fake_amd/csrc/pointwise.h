@@ -13,7 +13,7 @@ constexpr int PACK_MAX_LAYERS = 64;  // layers per kernel-argument table
 int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long count,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* mean, float* invstd,
-                       float* scale, float* shift, hipStream_t stream);
+                       float* scale, float* shift, hipStream_t stream, const NetSplit* ns = nullptr);
 // eval mode: scale/shift from the running statistics
 int bn_eval_coeff_launch(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift,
@@ -33,21 +33,21 @@ int bn_eval_coeff_all_launch(const float* params, const float* bnstats, void* ws
 // a = act(y*scale + shift + residual),  residual = res (activation) or yr*scale_r + shift_r
 int bn_apply_launch(int dtype, const void* y, const float* scale, const float* shift,
                     const void* res, const void* yr, const float* scale_r, const float* shift_r,
-                    int relu, void* out, long rows, int C, hipStream_t stream);
+                    int relu, void* out, long rows, int C, hipStream_t stream, const NetSplit* ns = nullptr);
 // backward: dz = dA * (a > 0 if a given);  partial sums of dz and dz*xhat
 int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
                          const float* mean, const float* invstd, float* partial, int* nblocks,
                          long rows, int C, hipStream_t stream, const float* mask_scale = nullptr,
-                         const float* mask_shift = nullptr);
+                         const float* mask_shift = nullptr, const NetSplit* ns = nullptr);
 int bn_bwd_reduce_blocks(long rows, int C, int dtype);
 int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
-                           int accumulate, float* coef /*[3][C]*/, hipStream_t stream);
+                           int accumulate, float* coef /*[3][C]*/, hipStream_t stream, const NetSplit* ns = nullptr);
 // dy = k1*(dz - k2 - xhat*k3); optionally dz -> dres (+= if dres_acc)
 int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
                         const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
                         long rows, int C, hipStream_t stream, const float* mask_scale = nullptr,
-                        const float* mask_shift = nullptr);
+                        const float* mask_shift = nullptr, const NetSplit* ns = nullptr);
 
 // bn_fused.hip: the finalize step folded into the streaming pass (fp32 tensors, C % 32 == 0, few partial rows)
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C);
@@ -55,24 +55,26 @@ int bn_finalize_apply_launch(int dtype, const float* stats, int stat_rows, int C
                              const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, float* mean, float* invstd, float* scale, float* shift,
                              const void* y, const void* res, const void* yr, const float* scale_r,
-                             const float* shift_r, int relu, void* out, long rows, hipStream_t stream);
+                             const float* shift_r, int relu, void* out, long rows, hipStream_t stream,
+                             const NetSplit* ns = nullptr, int plan_nets = 1);
 int bn_bwd_finalize_apply_launch(int dtype, const float* partial, int nblocks, int C, long count, const float* gamma,
                                  const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                  int accumulate, float* coef, const void* dA, const void* a, const void* y, void* dy,
                                  void* dres, int dres_acc, long rows, hipStream_t stream,
-                                 const float* mask_scale = nullptr, const float* mask_shift = nullptr);
+                                 const float* mask_scale = nullptr, const float* mask_shift = nullptr,
+                                 const NetSplit* ns = nullptr, int plan_nets = 1);
 
 // ---- pooling / resampling / layout (K6, K8 backward, boundary) ---------------------------
 int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
-                            int C, hipStream_t stream);
+                            int C, hipStream_t stream, const NetSplit* ns = nullptr);
 int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
-                            int B, int H, int W, int C, hipStream_t stream);
+                            int B, int H, int W, int C, hipStream_t stream, const NetSplit* ns = nullptr);
 // dlow[b,y,x,c] = sum of the 2x2 block of dfull  (backward of nearest x2 up-sampling)
 int sum2x2_launch(int dtype, const void* dfull, void* dlow, int B, int Hl, int Wl, int C,
-                  hipStream_t stream);
+                  hipStream_t stream, const NetSplit* ns = nullptr);
 // NCHW fp32 [B][C][H][W] -> NHWC T [B][H][W][Cpad] (pad channels zero) and back
 int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad,
-                        hipStream_t stream);
+                        hipStream_t stream, const NetSplit* ns = nullptr);
 int nhwc_to_nchw_launch(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cpad,
                         hipStream_t stream);
 

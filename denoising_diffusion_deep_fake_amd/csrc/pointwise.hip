@@ -73,8 +73,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ stats, int tiles, int C, int Cpad, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_o,
-    float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o) {
+    float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o, NetSplit ns) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): blockIdx.z = net
+    net_shift(stats, ns.ws); net_shift(gamma, ns.par); net_shift(beta, ns.par);
+    net_shift(running_mean, ns.bn); net_shift(running_var, ns.bn);
+    net_shift(mean_o, ns.ws); net_shift(invstd_o, ns.ws); net_shift(scale_o, ns.ws); net_shift(shift_o, ns.ws);
+  }
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < tiles; t += 256) {
@@ -104,10 +109,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 int bn_finalize_launch(const float* stats, int tiles, int C, int Cpad, long count,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* mean, float* invstd,
-                       float* scale, float* shift, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, stats, tiles, C,
+                       float* scale, float* shift, hipStream_t stream, const NetSplit* ns) {
+  const NetSplit nv = net_split_or_single(ns);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, 1, nv.nets), dim3(256), 0, stream, stats, tiles, C,
                      Cpad, (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                     invstd, scale, shift);
+                     invstd, scale, shift, nv);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -159,8 +165,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const T* __restrict__ res, const T* __restrict__ yr, const float* __restrict__ scale_r,
-    const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C) {
+    const float* __restrict__ shift_r, int relu, T* __restrict__ out, long nvec, int C, long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): every operand lives in the workspace
+    net_shift(y, net_ws); net_shift(scale, net_ws); net_shift(shift, net_ws); net_shift(res, net_ws); net_shift(yr, net_ws);
+    net_shift(scale_r, net_ws); net_shift(shift_r, net_ws); net_shift(out, net_ws);
+  }
   constexpr int N = V16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int c0 = (int)((i * N) % C);
@@ -196,20 +206,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 
 int bn_apply_launch(int dtype, const void* y, const float* scale, const float* shift,
                     const void* res, const void* yr, const float* scale_r, const float* shift_r,
-                    int relu, void* out, long rows, int C, hipStream_t stream) {
+                    int relu, void* out, long rows, int C, hipStream_t stream, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0 && (256 * ve) % C == 0, "bn_apply: C=%d must divide %d", C, 256 * ve);
   const long nvec = rows * C / ve;
   if (nvec == 0) return 0;
-  const int grid = grid_for(nvec);
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(grid_for(nvec), 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)y, scale,
+    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, stream, (const float*)y, scale,
                        shift, (const float*)res, (const float*)yr, scale_r, shift_r, relu, (float*)out,
-                       nvec, C);
+                       nvec, C, nv.ws);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)y,
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)y,
                        scale, shift, (const bf16_t*)res, (const bf16_t*)yr, scale_r, shift_r, relu,
-                       (bf16_t*)out, nvec, C);
+                       (bf16_t*)out, nvec, C, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -236,8 +247,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
-    long rows, int C, const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
+    long rows, int C, const float* __restrict__ mask_scale, const float* __restrict__ mask_shift, long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): every operand lives in the workspace
+    net_shift(dA, net_ws); net_shift(a, net_ws); net_shift(y, net_ws); net_shift(mean, net_ws); net_shift(invstd, net_ws);
+    net_shift(partial, net_ws); net_shift(mask_scale, net_ws); net_shift(mask_shift, net_ws);
+  }
   constexpr int N = V16<T>::N;
   __shared__ float red[256 * N * 2];
   const int VC = C / N;        // vectors per row (power of two, <= 256)
@@ -314,21 +329,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y,
                          const float* mean, const float* invstd, float* partial, int* nblocks,
                          long rows, int C, hipStream_t stream, const float* mask_scale,
-                         const float* mask_shift) {
+                         const float* mask_shift, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   const int vc = C / ve;
   D3F_CHECK(C % ve == 0 && vc >= 1 && vc <= 256 && (256 % vc) == 0,
             "bn_bwd_reduce: unsupported channel count %d", C);
   const int blocks = bn_bwd_reduce_blocks(rows, C, dtype);
   *nblocks = blocks;
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(blocks, 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, stream,
                        (const float*)dA, (const float*)a, (const float*)y, mean, invstd, partial, rows, C,
-                       mask_scale, mask_shift);
+                       mask_scale, mask_shift, nv.ws);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, stream,
                        (const bf16_t*)dA, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, partial, rows, C,
-                       mask_scale, mask_shift);
+                       mask_scale, mask_shift, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -336,8 +353,12 @@ int bn_bwd_reduce_launch(int dtype, const void* dA, const void* a, const void* y
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, NetSplit ns) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit)
+    net_shift(partial, ns.ws); net_shift(gamma, ns.par); net_shift(invstd, ns.ws);
+    net_shift(dgamma, ns.grad); net_shift(dbeta, ns.grad); net_shift(coef, ns.ws);
+  }
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < nblocks; t += 256) {
@@ -360,9 +381,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 
 int bn_bwd_finalize_launch(const float* partial, int nblocks, int C, long count,
                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
-                           int accumulate, float* coef, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblocks,
-                     C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+                           int accumulate, float* coef, hipStream_t stream, const NetSplit* ns) {
+  const NetSplit nv = net_split_or_single(ns);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, 1, nv.nets), dim3(256), 0, stream, partial, nblocks,
+                     C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef, nv);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -372,8 +394,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dA, const T* __restrict__ a, const T* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
     T* __restrict__ dy, T* __restrict__ dres, int dres_acc, long nvec, int C,
-    const float* __restrict__ mask_scale, const float* __restrict__ mask_shift) {
+    const float* __restrict__ mask_scale, const float* __restrict__ mask_shift, long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): every operand lives in the workspace
+    net_shift(dA, net_ws); net_shift(a, net_ws); net_shift(y, net_ws); net_shift(mean, net_ws); net_shift(invstd, net_ws);
+    net_shift(coef, net_ws); net_shift(dy, net_ws); net_shift(dres, net_ws); net_shift(mask_scale, net_ws);
+    net_shift(mask_shift, net_ws);
+  }
   constexpr int N = V16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int c0 = (int)((i * N) % C);
@@ -411,20 +438,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y, const float* mean,
                         const float* invstd, const float* coef, void* dy, void* dres, int dres_acc,
                         long rows, int C, hipStream_t stream, const float* mask_scale,
-                        const float* mask_shift) {
+                        const float* mask_shift, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0 && (256 * ve) % C == 0, "bn_bwd_apply: C=%d must divide %d", C, 256 * ve);
   const long nvec = rows * C / ve;
   if (nvec == 0) return 0;
-  const int grid = grid_for(nvec);
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(grid_for(nvec), 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)dA,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, stream, (const float*)dA,
                        (const float*)a, (const float*)y, mean, invstd, coef, (float*)dy, (float*)dres,
-                       dres_acc, nvec, C, mask_scale, mask_shift);
+                       dres_acc, nvec, C, mask_scale, mask_shift, nv.ws);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dA,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)dA,
                        (const bf16_t*)a, (const bf16_t*)y, mean, invstd, coef, (bf16_t*)dy, (bf16_t*)dres,
-                       dres_acc, nvec, C, mask_scale, mask_shift);
+                       dres_acc, nvec, C, mask_scale, mask_shift, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -435,8 +463,11 @@ int bn_bwd_apply_launch(int dtype, const void* dA, const void* a, const void* y,
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                           uint8_t* __restrict__ idx, int B, int H,
-                                                          int W, int C) {
+                                                          int W, int C, long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit)
+    net_shift(in, net_ws); net_shift(out, net_ws); net_shift(idx, net_ws);
+  }
   constexpr int N = V16<T>::N;
   const int Ho = H / 2, Wo = W / 2, VC = C / N;
   const long total = (long)B * Ho * Wo * VC;
@@ -486,8 +517,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout,
                                                           const uint8_t* __restrict__ idx,
                                                           T* __restrict__ din, int accumulate, int B,
-                                                          int H, int W, int C, unsigned vc_mul, unsigned vc_shr) {
+                                                          int H, int W, int C, unsigned vc_mul, unsigned vc_shr,
+                                                          long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit)
+    net_shift(dout, net_ws); net_shift(idx, net_ws); net_shift(din, net_ws);
+  }
   constexpr int N = V16<T>::N;
   const int Ho = H / 2, Wo = W / 2, VC = C / N;
   const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;  // (ix, cv) in the row
@@ -540,38 +575,41 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 int maxpool3x3s2_fwd_launch(int dtype, const void* in, void* out, uint8_t* idx, int B, int H, int W,
-                            int C, hipStream_t stream) {
+                            int C, hipStream_t stream, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: shape (%d,%d,%d)", H, W, C);
   const long total = (long)B * (H / 2) * (W / 2) * (C / ve);
   if (total == 0) return 0;
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(grid_for(total), 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const float*)in, (float*)out, idx, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, stream,
+                       (const float*)in, (float*)out, idx, B, H, W, C, nv.ws);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const bf16_t*)in, (bf16_t*)out, idx, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream,
+                       (const bf16_t*)in, (bf16_t*)out, idx, B, H, W, C, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
 
 int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, void* din, int accumulate,
-                            int B, int H, int W, int C, hipStream_t stream) {
+                            int B, int H, int W, int C, hipStream_t stream, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: shape (%d,%d,%d)", H, W, C);
+  const NetSplit nv = net_split_or_single(ns);
   const long total = (long)B * H * W * (C / ve);
   if (total == 0) return 0;
   const int vc = C / ve;
   unsigned vc_mul, vc_shr;
   fast_div_setup((unsigned)vc, &vc_mul, &vc_shr);
   D3F_CHECK((long)B * H <= 65535, "maxpool backward: %d rows exceed the grid", B * H);
-  const dim3 grid((unsigned)cdiv((long)W * vc, 256), (unsigned)(B * H));
+  const dim3 grid((unsigned)cdiv((long)W * vc, 256), (unsigned)(B * H), (unsigned)nv.nets);
   if (dtype == D3F_F32)
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, stream,
-                       (const float*)dout, idx, (float*)din, accumulate, B, H, W, C, vc_mul, vc_shr);
+                       (const float*)dout, idx, (float*)din, accumulate, B, H, W, C, vc_mul, vc_shr, nv.ws);
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream,
-                       (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, B, H, W, C, vc_mul, vc_shr);
+                       (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, B, H, W, C, vc_mul, vc_shr, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -581,8 +619,11 @@ int maxpool3x3s2_bwd_launch(int dtype, const void* dout, const uint8_t* idx, voi
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sum2x2_kernel(const T* __restrict__ dfull, T* __restrict__ dlow,
-                                                     int B, int Hl, int Wl, int C) {
+                                                     int B, int Hl, int Wl, int C, long net_ws) {
   chain_priority();
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit)
+    net_shift(dfull, net_ws); net_shift(dlow, net_ws);
+  }
   constexpr int N = V16<T>::N;
   const int VC = C / N;
   const long total = (long)B * Hl * Wl * VC;
@@ -609,17 +650,19 @@ __global__ __launch_bounds__(256) void sum2x2_kernel(const T* __restrict__ dfull
 }
 
 int sum2x2_launch(int dtype, const void* dfull, void* dlow, int B, int Hl, int Wl, int C,
-                  hipStream_t stream) {
+                  hipStream_t stream, const NetSplit* ns) {
   const int ve = dtype == D3F_F32 ? 4 : 8;
   D3F_CHECK(C % ve == 0, "sum2x2: C=%d", C);
   const long total = (long)B * Hl * Wl * (C / ve);
   if (total == 0) return 0;
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(grid_for(total), 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(sum2x2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const float*)dfull, (float*)dlow, B, Hl, Wl, C);
+    hipLaunchKernelGGL(sum2x2_kernel<float>, grid, dim3(256), 0, stream,
+                       (const float*)dfull, (float*)dlow, B, Hl, Wl, C, nv.ws);
   else
-    hipLaunchKernelGGL(sum2x2_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const bf16_t*)dfull, (bf16_t*)dlow, B, Hl, Wl, C);
+    hipLaunchKernelGGL(sum2x2_kernel<bf16_t>, grid, dim3(256), 0, stream,
+                       (const bf16_t*)dfull, (bf16_t*)dlow, B, Hl, Wl, C, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }
@@ -630,7 +673,10 @@ int sum2x2_launch(int dtype, const void* dfull, void* dlow, int B, int Hl, int W
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
                                                            T* __restrict__ out, int B, int C, long HW,
-                                                           int Cpad) {
+                                                           int Cpad, long net_in, long net_ws) {
+  if (blockIdx.z != 0) {  // two networks in one launch (common.h, NetSplit): boundary tensor in, workspace tensor out
+    net_shift(in, net_in); net_shift(out, net_ws);
+  }
   const long total = (long)B * HW;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long b = i / HW, pix = i - b * HW;
@@ -782,15 +828,17 @@ int nchw_to_u8bgr_launch(const float* in, uint8_t* out, int B, long HW, const fl
 }
 
 int nchw_to_nhwc_launch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cpad,
-                        hipStream_t stream) {
+                        hipStream_t stream, const NetSplit* ns) {
   const long total = (long)B * H * W;
   if (total == 0) return 0;
+  const NetSplit nv = net_split_or_single(ns);
+  const dim3 grid(grid_for(total), 1, nv.nets);
   if (dtype == D3F_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, in,
-                       (float*)out, B, C, (long)H * W, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, stream, in,
+                       (float*)out, B, C, (long)H * W, Cpad, nv.in, nv.ws);
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, in,
-                       (bf16_t*)out, B, C, (long)H * W, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, stream, in,
+                       (bf16_t*)out, B, C, (long)H * W, Cpad, nv.in, nv.ws);
   D3F_HIP(hipGetLastError());
   return 0;
 }

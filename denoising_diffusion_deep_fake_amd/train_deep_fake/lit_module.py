@@ -4,7 +4,10 @@ Mirrors d3f/train_deep_fake/lit_module.py:30-300: two U-Nets (`model_a`, `model_
 optimisers alternated by `optimizer_idx`, `mode: "denoise"` (noisy real -> real) or `mode: "swap"`
 (EMA teacher of the OTHER domain renders a fake, the student denoises the noised fake back to the
 real image), and the single-frame inference entry `predict_fake`.  Same hyper-parameter keys as
-denoise_config.yml / swap_config.yml; extra optional keys: `synthetic`, `image_size`, `precision`, `augment`.
+denoise_config.yml / swap_config.yml; extra optional keys: `synthetic`, `image_size`, `precision`, `augment`,
+`pair_fused` (denoise mode: the two nets' optimizer steps of a batch as ONE set of kernel launches -- UnetPair; default on,
+`false` = Lightning's one-after-the-other loop) and `pair_plan` (the sequential loop on the pair's kernel choices: the
+bit-identical reference of the fused step).
 
 Augmentation: the reference's `A.ShiftScaleRotate(shift_limit=0.2, scale_limit=0.1, rotate_limit=15, border_mode=0,
 p=0.7)` after `A.Normalize` (lit_module.py:99-111) runs on the GPU here -- per-sample Bernoulli(0.7), the same
@@ -32,7 +35,7 @@ from ..lightning import LightningModule
 from ..loss_functions import MseStructuralSimilarityLoss
 from ..optim import EMA, FusedAdam
 from ..trainer import LearningRateMonitor, ModelCheckpoint
-from ..unet import Unet
+from ..unet import Unet, UnetPair
 
 
 class ShiftScaleRotate(nn.Module):
@@ -77,6 +80,10 @@ class LitModule(LightningModule):
         self.augmentation = self.create_gpu_augmentation()
         self.model_a = self.create_model_instance()
         self.model_b = self.create_model_instance()
+        if self.hparams.get("pair_plan", False):
+            self.model_a.set_plan_nets(2)
+            self.model_b.set_plan_nets(2)
+        self.__dict__["_pair"] = None  # UnetPair(model_a, model_b), made on first use (not a sub-module: no state of its own)
         self.ema_model_a = self.create_ema_model(self.model_a)
         self.ema_model_b = self.create_ema_model(self.model_b)
         self.criterion = MseStructuralSimilarityLoss(-1.0, 1.0)
@@ -193,6 +200,55 @@ class LitModule(LightningModule):
             loss = self.training_step_for_one_model("b", batch_b, self.model_b, self.ema_model_a)
         self.log("epoch", float(self.current_epoch))
         return loss
+
+    # ---- the two optimizer steps of a denoise-mode batch as one set of launches ------------------------------------
+    def pair_fused_active(self, batch=None, optimizers=None):
+        """In `mode: "denoise"` optimizer 0 trains model_a on batch a and optimizer 1 trains model_b on batch b, nothing
+        shared (d3f/train_deep_fake/lit_module.py:142-181): the trainer may run both steps as ONE forward / backward of a
+        UnetPair (trainer.optimizer_steps).  Not in swap mode (each step updates and runs the OTHER net's EMA teacher,
+        :183-206), not with `pair_fused: false`, not for a ragged batch pair, synchronised BatchNorm statistics or
+        optimisers other than the two FusedAdam of configure_optimizers."""
+        p = self.hparams
+        if p.mode != "denoise" or p.get("pair_fused", None) is False or p.get("concurrent_optimizers", False):
+            return False
+        if optimizers is not None:
+            if len(optimizers) != 2 or not all(isinstance(o, FusedAdam) for o in optimizers) or \
+                    optimizers[0].module is not self.model_a or optimizers[1].module is not self.model_b:
+                return False
+        if batch is not None:
+            a, b = batch["a"]["image"], batch["b"]["image"]
+            if a.shape != b.shape or a.dtype != b.dtype or a.device.type != "cuda":
+                return False
+        if not (self.model_a.training and self.model_b.training):
+            return False
+        return not (self.model_a._rt.get("bn_sync") or self.model_b._rt.get("bn_sync"))
+
+    def training_step_pair(self, batch, batch_idx):
+        """training_step(batch, batch_idx, 0) and training_step(batch, batch_idx, 1) of a denoise-mode batch as one pass:
+        the same preparation and the same random draws in the same order (a's augmentation and noise, then b's), ONE
+        forward of UnetPair(model_a, model_b), the two losses.  Returns (loss_a, loss_b); the caller runs ONE backward,
+        torch.autograd.backward([loss_a, loss_b]), then both optimizer steps."""
+        p = self.hparams
+        reals, noisy = [], []
+        for key, mean in (("a", p.mean_a), ("b", p.mean_b)):
+            x = batch[key]["image"]
+            if x.dtype == torch.uint8:
+                x = ops.u8rgb_normalise(x, mean, mean)
+            if self.augmentation is not None:
+                x = self.augmentation(x)
+            with torch.no_grad():
+                noisy.append(self.blend_random_amount_of_noise_with_each_sample(x))
+            reals.append(x)
+        if self._pair is None:
+            self.__dict__["_pair"] = UnetPair(self.model_a, self.model_b)
+        predictions = self._pair(noisy[0], noisy[1])
+        losses = []
+        for name, prediction, real in zip("ab", predictions, reals):
+            loss = self.criterion(prediction, real)
+            self.log(f"loss_denoise/train_{name}", loss)
+            losses.append(loss)
+        self.log("epoch", float(self.current_epoch))
+        return tuple(losses)
 
     def training_step_for_one_model(self, name, real, real_model, fake_model):
         p = self.hparams

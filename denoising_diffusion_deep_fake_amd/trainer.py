@@ -186,6 +186,19 @@ def optimizer_steps(model, optimizers, opt_params, batch, batch_idx, takes_idx, 
     of one batch overlap on the GPU -- at bs 8 per net a single step leaves more than half of the chip idle -- while
     every value stays what the sequential loop computes (the random draws keep their host order)."""
     multi = len(optimizers) > 1
+    if multi and not streams and takes_idx and hasattr(model, "training_step_pair") and \
+            model.pair_fused_active(batch, optimizers):
+        # two INDEPENDENT optimizer steps (train_deep_fake's denoise mode) as one set of kernel launches: one forward and
+        # one backward of the module's UnetPair, then both optimizer steps -- the values of the loop below, the launches
+        # of one 16-image step instead of two 8-image ones.  (Every parameter already requires grad here: the toggles
+        # of the loop are undone at its end.)
+        for opt in optimizers:
+            opt.zero_grad(set_to_none=True)
+        losses = model.training_step_pair(batch, batch_idx)
+        torch.autograd.backward(list(losses))
+        for opt in optimizers:
+            opt.step()
+        return losses[-1]
     current = torch.cuda.current_stream() if streams else None
     for oi, opt in enumerate(optimizers):
         if streams:

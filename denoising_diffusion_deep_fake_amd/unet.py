@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import D3FError, check, ptr, stream_ptr
+from ._lib import D3FError, check, ptr, ptr2, stream_ptr
 
 _DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
            "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16,
@@ -96,10 +96,16 @@ _ENCODERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
 class _Engine:
     """one libd3f_hip whole-network plan + its workspace, for a fixed (B, H, W, dtype)."""
 
-    def __init__(self, encoder_name, in_channels, classes, B, H, W, dtype, device):
+    def __init__(self, encoder_name, in_channels, classes, B, H, W, dtype, device, nets=1, plan_nets=1):
         L = _lib.lib()
         self.h = C.c_void_p()
-        check(L.d3f_unet_create(encoder_name.encode(), in_channels, classes, B, H, W, dtype, C.byref(self.h)))
+        if nets == 1 and plan_nets == 1:
+            check(L.d3f_unet_create(encoder_name.encode(), in_channels, classes, B, H, W, dtype, C.byref(self.h)))
+        else:  # a pair (nets = 2: B images PER network), or one network planned like the pair (plan_nets = 2)
+            check(L.d3f_unet_create_nets(encoder_name.encode(), in_channels, classes, B, H, W, dtype, nets, plan_nets,
+                                         C.byref(self.h)))
+        self.nets = nets
+        self.net_stride = L.d3f_unet_net_workspace_stride(self.h)
         self.shape = (B, H, W)
         self.dtype = dtype
         self.workspace = torch.empty(L.d3f_unet_workspace_bytes(self.h), dtype=torch.uint8, device=device)
@@ -245,6 +251,7 @@ class Unet(nn.Module):
             raise ValueError(f"compute_dtype must be one of f32 / f32x3 / bf16, got {compute_dtype}")
         self.encoder_name, self.in_channels, self.classes = encoder_name, in_channels, classes
         self.compute_dtype = _DTYPES[compute_dtype]
+        self.plan_nets = 1  # set_plan_nets(2): this network's kernels are chosen as for a UnetPair (bit-identity runs)
         self.encoder = _Encoder(in_channels, _ENCODERS[encoder_name])
         self.decoder = _Decoder()
         self.segmentation_head = nn.Sequential(nn.Conv2d(16, classes, 3, padding=1), nn.Identity(), nn.Identity())
@@ -347,6 +354,18 @@ class Unet(nn.Module):
         for p in named.values():
             p.grad = None
 
+    def set_plan_nets(self, plan_nets):
+        """plan_nets = 2: every plan of this network makes the tile / split-K / slab / patch-kernel choices of a UnetPair
+        (the workgroups of two networks counted together), so that stepping it alone computes bit for bit what the pair
+        computes for it -- the reference side of the pair's bit-identity test.  Drops the existing plans."""
+        if plan_nets not in (1, 2):
+            raise ValueError("plan_nets must be 1 or 2")
+        if plan_nets != getattr(self, "plan_nets", 1):
+            self.plan_nets = plan_nets
+            self._rt["engines"] = {}
+            self._rt.pop("last_engine", None)
+        return self
+
     def mark_params_changed(self):
         """call after writing the flat parameter buffer behind autograd's back (fused Adam / EMA)."""
         self._rt["dirty"] = True
@@ -433,7 +452,7 @@ class Unet(nn.Module):
         """a plan + workspace for this shape whose activations no live autograd graph still needs.  smp.Unet allows
         `crit(net(x1)) + crit(net(x2))` and a no_grad forward between forward and backward: each recorded forward
         leases its workspace until its backward has run, and a further forward of the same shape gets another one."""
-        key = (B, H, W, self.compute_dtype, device.index)
+        key = (B, H, W, self.compute_dtype, device.index, getattr(self, "plan_nets", 1))
         pool = self._rt["engines"].setdefault(key, [])
         for eng in pool:
             if not eng.in_use:
@@ -441,7 +460,8 @@ class Unet(nn.Module):
         if len(pool) >= self.MAX_LIVE_GRAPHS:
             raise D3FError(f"{len(pool)} forward passes of shape {(B, H, W)} are waiting for their backward pass; "
                            f"run inference-only forwards under torch.no_grad()")
-        eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device)
+        eng = _Engine(self.encoder_name, self.in_channels, self.classes, B, H, W, self.compute_dtype, device,
+                      plan_nets=getattr(self, "plan_nets", 1))
         if self._rt.get("bn_sync"):
             eng.set_bn_sync(*self._rt["bn_sync"])
         pool.append(eng)
@@ -477,14 +497,8 @@ class Unet(nn.Module):
         rt = self._rt
         L = _lib.lib()
         grad_out = grad_out.contiguous().float()
-        params = self._param_list
-        direct = all(p.grad is None for p in params)
-        if rt["flat_grad"] is None:
-            rt["flat_grad"] = torch.empty_like(rt["flat"])
-            rt["grad_views"] = None
-        target = rt["flat_grad"] if direct else torch.empty_like(rt["flat"])
+        target, direct = self._backward_target()
         sync = rt["grad_sync"]
-        rt["backward_calls"] = rt.get("backward_calls", 0) + 1
         early = rt.get("early_update") if (sync is None and direct and eng.nseg > 1) else None
         side = eng.side_stream(grad_out.device) if early is not None else None
         if early is not None and side is not None:
@@ -526,6 +540,22 @@ class Unet(nn.Module):
                     with torch.cuda.stream(side):
                         sync(k, target[b:e])
             check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
+        self._publish_grads(target, direct)
+
+    def _backward_target(self):
+        """(flat buffer the engine writes this pass's gradients into, direct): direct = every .grad is None, the gradients
+        land in the module's own flat gradient buffer and the parameters' .grad become views of it"""
+        rt = self._rt
+        direct = all(p.grad is None for p in self._param_list)
+        if rt["flat_grad"] is None:
+            rt["flat_grad"] = torch.empty_like(rt["flat"])
+            rt["grad_views"] = None
+        rt["backward_calls"] = rt.get("backward_calls", 0) + 1
+        return (rt["flat_grad"] if direct else torch.empty_like(rt["flat"])), direct
+
+    def _publish_grads(self, target, direct):
+        rt = self._rt
+        params = self._param_list
         ptable = self._table()[0]
         if direct:
             # the same 143 view tensors of the flat gradient buffer every step (making them anew cost ~0.3 ms of host time)
@@ -667,3 +697,184 @@ class Unet(nn.Module):
             device = torch.device("cuda", torch.cuda.current_device())
         eng = self._engine(B, H, W, device)
         return eng.fwd_flops, eng.bwd_flops
+
+
+# ---------------------------------------------------------------------------------------------
+# two networks, one set of launches
+# ---------------------------------------------------------------------------------------------
+class _UnetPairFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xa, xb, pair, engine, anchor_a, anchor_b):
+        ctx.pair, ctx.engine = pair, engine
+        out = pair._run_forward(engine, xa, xb)
+        ctx.serial = engine.serial
+        ctx.lease = _Lease(engine)
+        return out
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        eng = ctx.engine
+        if ctx.lease.engine is None:
+            raise D3FError("backward through the d3f UnetPair a second time: the activations were released by the first "
+                           "backward (retain_graph is not supported by the HIP path)")
+        if ctx.serial != eng.serial:
+            raise D3FError("the workspace of this pair forward was overwritten by a later forward before backward ran")
+        # (autograd materialises the gradient of an output the loss does not depend on as zeros: that network's
+        # parameter gradients then come out as exact zeros)
+        ctx.pair._run_backward(eng, ga, gb)
+        ctx.lease.release()
+        return (None,) * 6
+
+
+class UnetPair:
+    """Two `Unet`s of identical architecture stepped as ONE set of kernel launches.
+
+    train_deep_fake's `mode: "denoise"` trains model_a on domain a and model_b on domain b with nothing shared
+    (d3f/train_deep_fake/lit_module.py:142-181): two independent forward / backward passes of 8 images each per batch, every
+    launch half-filling the chip.  `UnetPair(model_a, model_b)(xa, xb)` runs both networks' layer k as one launch
+    (libd3f_hip.so: d3f_unet_pair_forward / d3f_unet_pair_backward -- gridDim.z carries the network) with the tile choices
+    of a 16-image batch, and returns (prediction_a, prediction_b) wired into autograd: ONE backward pass fed both output
+    gradients, `torch.autograd.backward([loss_a, loss_b])`, writes both networks' .grad.  The two modules keep their own
+    parameters, gradients, BatchNorm statistics and optimisers; values are bit for bit those of each network stepped alone
+    with `Unet.set_plan_nets(2)`.  Train mode, per-GPU BatchNorm statistics."""
+
+    def __init__(self, net_a, net_b):
+        if not (isinstance(net_a, Unet) and isinstance(net_b, Unet)) or net_a is net_b:
+            raise TypeError("UnetPair takes two distinct d3f Unet modules")
+        for attr in ("encoder_name", "in_channels", "classes", "compute_dtype"):
+            if getattr(net_a, attr) != getattr(net_b, attr):
+                raise ValueError(f"UnetPair: the two networks differ in {attr}")
+        self.nets = (net_a, net_b)
+        self._engines = {}
+        self.last_engine = None
+
+    def _engine(self, B, H, W, device):
+        a = self.nets[0]
+        key = (B, H, W, a.compute_dtype, device.index)
+        pool = self._engines.setdefault(key, [])
+        for eng in pool:
+            if not eng.in_use:
+                return eng
+        if len(pool) >= Unet.MAX_LIVE_GRAPHS:
+            raise D3FError(f"{len(pool)} pair forward passes of shape {(B, H, W)} are waiting for their backward pass")
+        eng = _Engine(a.encoder_name, a.in_channels, a.classes, B, H, W, a.compute_dtype, device, nets=2, plan_nets=2)
+        pool.append(eng)
+        return eng
+
+    def _pack_if_needed(self, eng):
+        vers = []
+        for net in self.nets:
+            rt = net._rt
+            vers.append(sum(p._version for p in rt["params"]) + rt["flat"]._version)
+            if rt["dirty"]:  # (the networks' own single plans are stale too; the flag is theirs to clear)
+                for pool in rt["engines"].values():
+                    for e in pool:
+                        e.packed_version = None
+                rt["dirty"] = False
+                for pool in self._engines.values():
+                    for e in pool:
+                        e.packed_version = None
+        ver = tuple(vers)
+        if eng.packed_version != ver:
+            a, b = self.nets
+            check(_lib.lib().d3f_unet_pair_pack_weights(eng.h, ptr2(a._rt["flat"], b._rt["flat"]), ptr(eng.workspace),
+                                                        stream_ptr()))
+            eng.packed_version = ver
+
+    def _run_forward(self, eng, xa, xb):
+        a, b = self.nets
+        self._pack_if_needed(eng)
+        shape = (xa.shape[0], a.classes, xa.shape[2], xa.shape[3])
+        oa = torch.empty(shape, dtype=torch.float32, device=xa.device)
+        ob = torch.empty(shape, dtype=torch.float32, device=xa.device)
+        eng.serial += 1
+        self.last_engine = eng
+        check(_lib.lib().d3f_unet_pair_forward(eng.h, ptr2(a._rt["flat"], b._rt["flat"]),
+                                               ptr2(a._rt["flat_bn"], b._rt["flat_bn"]), ptr2(xa, xb), ptr2(oa, ob),
+                                               ptr(eng.workspace), stream_ptr()))
+        for net in self.nets:
+            net._rt["flat_nbt"] += 1
+        return oa, ob
+
+    def _run_backward(self, eng, ga, gb):
+        a, b = self.nets
+        L = _lib.lib()
+        ga, gb = ga.contiguous().float(), gb.contiguous().float()
+        (ta, da), (tb, db) = a._backward_target(), b._backward_target()
+        params, douts, grads = ptr2(a._rt["flat"], b._rt["flat"]), ptr2(ga, gb), ptr2(ta, tb)
+        syncs = (a._rt["grad_sync"], b._rt["grad_sync"])
+        if syncs[0] is None and syncs[1] is None:
+            check(L.d3f_unet_pair_backward(eng.h, params, douts, grads, ptr(eng.workspace), 0, eng.nseg, 1, stream_ptr()))
+        else:
+            # data parallel (as Unet._run_backward): bucket k's collectives -- one per network, each module's own reducer
+            # -- wait for bucket k's gradients on the engine's side stream, the chain goes straight on with bucket k + 1
+            if syncs[0] is None or syncs[1] is None:
+                raise D3FError("UnetPair: attach the data-parallel reducer to both networks or to neither")
+            if a._rt.get("grad_buckets") != b._rt.get("grad_buckets"):
+                raise D3FError("UnetPair: the two networks' gradient bucket settings differ")
+            side = eng.side_stream(ga.device)
+            for k, (s0, s1) in enumerate(Unet._bucket_groups(a._rt.get("grad_buckets"), eng.nseg)):
+                check(L.d3f_unet_pair_backward(eng.h, params, douts, grads, ptr(eng.workspace), s0, s1, 0, stream_ptr()))
+                lo, hi = min(r[0] for r in eng.seg_ranges[s0:s1]), max(r[1] for r in eng.seg_ranges[s0:s1])
+                if sum(r[1] - r[0] for r in eng.seg_ranges[s0:s1]) != hi - lo:
+                    raise D3FError(f"gradient bucket {k}: segments {s0}..{s1 - 1} are not one contiguous flat range")
+                with (torch.cuda.stream(side) if side is not None else _nullcontext()):
+                    syncs[0](k, ta[lo:hi])
+                    syncs[1](k, tb[lo:hi])
+            check(L.d3f_unet_backward_join(eng.h, stream_ptr()))
+        a._publish_grads(ta, da)
+        b._publish_grads(tb, db)
+
+    def usable(self, xa, xb):
+        """can this batch go through the pair?  Same shape, both networks training on one HIP device, and neither with
+        synchronised BatchNorm statistics (the pair engine keeps per-GPU statistics)"""
+        a, b = self.nets
+        return (xa.shape == xb.shape and xa.device == xb.device and xa.device.type == "cuda" and a.training and b.training
+                and not a._rt.get("bn_sync") and not b._rt.get("bn_sync"))
+
+    def __call__(self, xa, xb):
+        a, b = self.nets
+        if xa.shape != xb.shape or xa.dim() != 4 or xa.shape[1] != a.in_channels:
+            raise RuntimeError(f"UnetPair expects two inputs of one shape [B, {a.in_channels}, H, W], got "
+                               f"{list(xa.shape)} and {list(xb.shape)}")
+        a.check_input_shape(xa)
+        if xa.device.type != "cuda" or xb.device != xa.device:
+            raise D3FError("d3f UnetPair runs on one MI355X (HIP) device; there is no CPU fallback")
+        if not (a.training and b.training):
+            raise D3FError("UnetPair runs the train-mode passes of train_deep_fake's denoise step; eval-mode inference "
+                           "goes through each Unet")
+        if a._rt.get("bn_sync") or b._rt.get("bn_sync"):
+            raise D3FError("UnetPair keeps per-GPU BatchNorm statistics; switch set_sync_batchnorm off or step the networks alone")
+        for net in self.nets:
+            net._ensure_flat(xa.device)
+        xa, xb = xa.detach().contiguous().float(), xb.detach().contiguous().float()
+        eng = self._engine(xa.shape[0], xa.shape[2], xa.shape[3], xa.device)
+        need = [any(p.requires_grad for p in net._param_list) for net in self.nets]
+        if torch.is_grad_enabled() and any(need):
+            if not all(need):
+                raise D3FError("UnetPair: both networks (or neither) must require gradients")
+            if xa.requires_grad or xb.requires_grad:
+                raise D3FError("gradient w.r.t. the network input is not computed by the HIP path")
+            anchors = [next(p for p in net._param_list if p.requires_grad) for net in self.nets]
+            return _UnetPairFunction.apply(xa, xb, self, eng, anchors[0], anchors[1])
+        return self._run_forward(eng, xa, xb)
+
+    def export_activation(self, net_index, name):
+        """`Unet.export_activation` for network 0 / 1 of the most recent pair pass"""
+        eng = self.last_engine
+        if eng is None:
+            raise D3FError("export_activation() before any pair forward pass")
+        dims = (C.c_int32 * 3)()
+        check(_lib.lib().d3f_unet_export_shape(eng.h, name.encode(), dims))
+        out = torch.empty((eng.shape[0], dims[0], dims[1], dims[2]), dtype=torch.float32, device=eng.workspace.device)
+        ws = C.c_void_p(eng.workspace.data_ptr() + int(net_index) * eng.net_stride)
+        check(_lib.lib().d3f_unet_export(eng.h, name.encode(), ws, ptr(out), stream_ptr()))
+        return out
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False

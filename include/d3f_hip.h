@@ -69,6 +69,38 @@ int d3f_unet_create(const char* encoder_name, int in_channels, int classes, int 
                     int dtype, d3f_unet_t* out);
 int d3f_unet_destroy(d3f_unet_t h);
 
+/* ---------------------------------------------------------------------------------------
+ * Two networks, one set of launches.
+ * Replaces: the two optimizer steps of one train_deep_fake batch in `mode: "denoise"` --
+ *           training_step(batch, batch_idx, optimizer_idx = 0 | 1) -> training_denoise_step_for_one_model("a", batch_a,
+ *           model_a) / ("b", batch_b, model_b), d3f/train_deep_fake/lit_module.py:142-181 -- whose forward and backward
+ *           passes are INDEPENDENT (model_a never sees domain b) and identical in shape, 8 images each: half of what
+ *           fills an MI355X.  A pair handle runs both networks' layer k as ONE kernel launch (gridDim.z carries the
+ *           network; a workgroup of network 1 adds byte offsets to its pointers), so every launch has the occupancy of a
+ *           16-image batch.  Results are bit for bit those of a single handle created with plan_nets = 2 and run net by
+ *           net; swap mode (coupled through the EMA teachers, :183-206) stays sequential.
+ * d3f_unet_create_nets: nets = 1 | 2 networks per launch, B images PER network; plan_nets (>= nets): the tile / split-K /
+ *           slab / patch-kernel choices count the workgroups of plan_nets networks (nets = 1, plan_nets = 2: the pair's
+ *           kernels on one network -- the reference run of the bit-identity test).  d3f_unet_create == (1, 1).
+ * Workspace of a pair: ONE buffer of d3f_unet_workspace_bytes(h) bytes = two copies of the single-network layout,
+ *           d3f_unet_net_workspace_stride(h) bytes apart (d3f_unet_export on network 1: pass workspace + stride).
+ * The pair entry points take the two networks' buffers as arrays of two pointers (any two allocations); train-mode
+ *           forward only, per-GPU BatchNorm statistics only (d3f_unet_set_bn_sync is refused).  Packing, forward and
+ *           backward of a pair handle go through these three calls; everything per network (noise blend, loss, Adam,
+ *           EMA) stays the single-network entry points, called once per network.
+ * ------------------------------------------------------------------------------------- */
+int d3f_unet_create_nets(const char* encoder_name, int in_channels, int classes, int B, int H, int W, int dtype,
+                         int nets, int plan_nets, d3f_unet_t* out);
+int d3f_unet_nets(d3f_unet_t h);
+size_t d3f_unet_net_workspace_stride(d3f_unet_t h);
+int d3f_unet_pair_pack_weights(d3f_unet_t h, const float* const params[2], void* workspace, void* stream);
+int d3f_unet_pair_forward(d3f_unet_t h, const float* const params[2], float* const bnstats[2], const float* const x[2],
+                          float* const out[2], void* workspace, void* stream);
+/* join != 0: every gradient of the segments is final on `stream` on return (d3f_unet_backward); join == 0: the
+ * d3f_unet_backward_nojoin contract (final on the engine's side stream; d3f_unet_backward_join later) */
+int d3f_unet_pair_backward(d3f_unet_t h, const float* const params[2], const float* const grad_out[2],
+                           float* const grads[2], void* workspace, int seg_begin, int seg_end, int join, void* stream);
+
 /* parameter table, in torch named_parameters() order; offsets are in floats into ONE flat
  * f32 buffer that holds every parameter (gradients use the same layout). */
 int d3f_unet_num_params(d3f_unet_t h);

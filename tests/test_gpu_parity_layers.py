@@ -23,14 +23,12 @@ NOISE = 4.0
 PINNED_TOL = 2e-4
 
 
-def _layer_parity(dtype, B, H, W):
-    """forward layer by layer + mask-pinned float64 backward at one (B, H, W); returns (worst forward ratio, pinned flat)"""
-    import gc
+DS_NAMES = [f"encoder.layer{li}.0.downsample.0" for li in (2, 3, 4)]
 
+
+def _oracle_net(seed):
     import oracle
-    from oracle.pinned import RecordingReLU, conv_outputs, pinned_backward, swap_relus, unit_names
-    from denoising_diffusion_deep_fake_amd import Unet, ops
-    torch.manual_seed(7)
+    torch.manual_seed(seed)
     ref = oracle.Unet("resnet34", None, 3, 3, None).train()
     with torch.no_grad():
         for m in ref.modules():
@@ -38,6 +36,24 @@ def _layer_parity(dtype, B, H, W):
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.normal_(0, 0.1)
         ref.segmentation_head[0].bias.normal_(0, 0.1)
+    return ref
+
+
+def _exports(export, net, names):
+    """every unit's raw conv output, activation and activation gradient + the parameter gradients of one HIP network"""
+    hip_y = {n: export(n + ":y").cpu() for n in names + DS_NAMES}
+    hip_a = {n: export(n + ":a").cpu() for n in names}
+    hip_da = {n: export(n + ":da").cpu() for n in names}
+    hip_grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    return hip_y, hip_a, hip_da, hip_grads
+
+
+def _layer_parity(dtype, B, H, W):
+    """forward layer by layer + mask-pinned float64 backward at one (B, H, W); returns (worst forward ratio, pinned flat)"""
+    import oracle
+    from oracle.pinned import unit_names
+    from denoising_diffusion_deep_fake_amd import Unet, ops
+    ref = _oracle_net(7)
     net = Unet("resnet34", None, 3, 3, None, compute_dtype=dtype)
     net.load_state_dict(ref.state_dict())
     net = net.cuda().train()
@@ -48,20 +64,24 @@ def _layer_parity(dtype, B, H, W):
     pred = net(x.cuda())
     _, gout = ops.mse_ssim_loss(pred.detach(), oracle.synthetic_face_crops(B, (H, W), seed=18).cuda())
     pred.backward(gout)
-    hip_y = {n: net.export_activation(n + ":y").cpu() for n in names}
-    hip_a = {n: net.export_activation(n + ":a").cpu() for n in names}
-    hip_da = {n: net.export_activation(n + ":da").cpu() for n in names}
-    ds_names = [f"encoder.layer{li}.0.downsample.0" for li in (2, 3, 4)]
-    hip_y.update({n: net.export_activation(n + ":y").cpu() for n in ds_names})
-    hip_grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    hip = _exports(net.export_activation, net, names)
     pred, gout = pred.detach().cpu(), gout.cpu()
     del net
     torch.cuda.empty_cache()
+    return _against_the_oracle(f"{dtype} B={B} {H}x{W}", ref, x, pred, gout, *hip)
+
+
+def _against_the_oracle(tag, ref, x, pred, gout, hip_y, hip_a, hip_da, hip_grads):
+    """one HIP network's exported pass against its float64 oracle: the two gates of the module docstring"""
+    import gc
+
+    from oracle.pinned import RecordingReLU, conv_outputs, pinned_backward, swap_relus, unit_names
+    names, ds_names = unit_names(), DS_NAMES
 
     # ---- (i) forward, layer by layer, unpinned: hip vs float64, next to cpu-fp32 vs float64 ----
     ref64 = copy.deepcopy(ref).double()
     outs = {}
-    for tag, model, inp in (("f32", copy.deepcopy(ref), x), ("f64", ref64, x.double())):
+    for kind, model, inp in (("f32", copy.deepcopy(ref), x), ("f64", ref64, x.double())):
         acts = []
         swap_relus(model, lambda: RecordingReLU(acts))
         store, hooks = conv_outputs(model)
@@ -69,7 +89,7 @@ def _layer_parity(dtype, B, H, W):
             model(inp)
         for h in hooks:
             h.remove()
-        outs[tag] = (dict(store), dict(zip(names, acts)))
+        outs[kind] = (dict(store), dict(zip(names, acts)))
         assert len(acts) == len(names)
     worst = 0.0
     for n in names + ds_names:
@@ -102,9 +122,44 @@ def _layer_parity(dtype, B, H, W):
     assert not bad, bad
     flat = rel_l2(torch.cat([hip_grads[k].reshape(-1) for k in grads]), torch.cat([g.reshape(-1) for g in grads.values()]))
     assert flat < PINNED_TOL / 2, flat
-    print(f"[{dtype} B={B} {H}x{W}] forward worst hip/cpu-fp32 distance ratio {worst:.2f}; "
-          f"pinned flat gradient rel-L2 {flat:.2e}")
+    print(f"[{tag}] forward worst hip/cpu-fp32 distance ratio {worst:.2f}; pinned flat gradient rel-L2 {flat:.2e}")
     return worst, flat
+
+
+@pytest.mark.timeout(1500)
+def test_every_layer_of_both_networks_of_a_pair_8x256x256():
+    """BASELINE configs[3] as the trainer runs it since round 6: the two networks of train_deep_fake's denoise mode
+    (model_a on batch a, model_b on batch b, 8 images each: d3f/train_deep_fake/lit_module.py:142-181) stepped as ONE set of
+    launches (UnetPair: gridDim.z carries the network, the plan is the 16-image one).  Two different networks, two
+    different batches, one pair pass; then EACH network's exported tensors go through the same two gates as a single
+    network -- every conv output / activation against float64, every activation gradient and each of the 143 parameter
+    gradients against the mask-pinned float64 oracle at 2e-4.  A workgroup of network 1 that read network 0's weights,
+    statistics rows, coefficients, slabs or boundary tensors anywhere is O(1) in that layer."""
+    import oracle
+    from oracle.pinned import unit_names
+    from denoising_diffusion_deep_fake_amd import Unet, UnetPair, ops
+    B, S = 8, 256
+    names = unit_names()
+    refs = [_oracle_net(7), _oracle_net(8)]
+    nets = []
+    for ref in refs:
+        net = Unet("resnet34", None, 3, 3, None)
+        net.load_state_dict(ref.state_dict())
+        nets.append(net.cuda().train())
+    xs = [oracle.synthetic_face_crops(B, S, seed=17 + 10 * i) for i in range(2)]
+    tgts = [oracle.synthetic_face_crops(B, S, seed=18 + 10 * i).cuda() for i in range(2)]
+    pair = UnetPair(*nets)
+    preds = pair(xs[0].cuda(), xs[1].cuda())
+    gouts = [ops.mse_ssim_loss(p.detach(), t)[1] for p, t in zip(preds, tgts)]
+    torch.autograd.backward(list(preds), gouts)
+    assert nets[0].flat_grads.data_ptr() != nets[1].flat_grads.data_ptr()
+    hips = [_exports(lambda n, i=i: pair.export_activation(i, n), nets[i], names) for i in range(2)]
+    preds = [p.detach().cpu() for p in preds]
+    gouts = [g.cpu() for g in gouts]
+    del pair, nets
+    torch.cuda.empty_cache()
+    for i in range(2):
+        _against_the_oracle(f"pair network {i}, f32 B={B} {S}x{S}", refs[i], xs[i], preds[i], gouts[i], *hips[i])
 
 
 # (3, 64, 64): BASELINE configs[0]-sized plumbing case; the full-resolution 16-channel layers run conv_patch_kernel
