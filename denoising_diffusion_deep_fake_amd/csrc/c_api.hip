@@ -136,7 +136,9 @@ static int upfold_dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& lo
   return 0;
 }
 
-static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk) {
+// want_sum2: the caller takes dx0 of an up-sampled single source at the source's LOW resolution where a launch can sum the
+// 2x2 blocks itself (d3f_conv_desc::upsample0 == 2, or the availability query d3f_conv_upsample_summed)
+static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool allow_splitk, bool want_sum2) {
   if (int rc = desc_check(dtype, d)) return rc;
   const Geo g = geo(dtype, d);
   const int s2 = d->stride == 2;
@@ -160,8 +162,8 @@ static int dgrad_params(int dtype, const d3f_conv_desc* d, ConvParams& p, bool a
   p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1 - d->pad;
   p.M = d->B * d->H * d->W;
   // an up-sampled single source without folded weights: ask for the 2x2-summed gradient at the source's own resolution
-  // (kept by the plan only where a patch kernel serves it: d3f_conv_upsample_summed)
-  p.sum2 = (d->upsample0 && d->C1 == 0) ? 1 : 0;
+  // (kept by the plan only where a patch kernel serves it: d3f_conv_upsample_summed) -- only for a caller that said so
+  p.sum2 = (want_sum2 && d->upsample0 && d->C1 == 0) ? 1 : 0;
   return conv_igemm_plan(p, dtype, allow_splitk);
 }
 
@@ -459,7 +461,7 @@ int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d) {
 int d3f_conv_upsample_summed(int dtype, const d3f_conv_desc* d) {
   ConvParams p;
   if (d == nullptr || !d->upsample0 || desc_check(dtype, d) != 0 || desc_upfold(dtype, d)) return 0;
-  if (dgrad_params(dtype, d, p, false) != 0) return 0;
+  if (dgrad_params(dtype, d, p, false, true) != 0) return 0;
   return p.sum2 ? 1 : 0;
 }
 size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
@@ -469,7 +471,7 @@ size_t d3f_conv_workspace_bytes(int dtype, const d3f_conv_desc* d, int which) {
     if (upfold_dgrad_params(dtype, d, lo, sk, true) != 0) return 0;
     return std::max(conv_splitk_floats(lo), d->C1 > 0 ? conv_splitk_floats(sk) : (size_t)0) * sizeof(float);
   }
-  const int rc = which == 0 ? fwd_params(dtype, d, p, true) : dgrad_params(dtype, d, p, true);
+  const int rc = which == 0 ? fwd_params(dtype, d, p, true) : dgrad_params(dtype, d, p, true, d != nullptr && d->upsample0 == 2);
   return rc != 0 ? 0 : conv_splitk_floats(p) * sizeof(float);
 }
 size_t d3f_conv_stats_floats(int dtype, const d3f_conv_desc* d, int with_workspace, int* tiles) {
@@ -560,7 +562,7 @@ int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, co
     }
     return 0;
   }
-  if (int rc = dgrad_params(dtype, d, p, workspace != nullptr)) return rc;
+  if (int rc = dgrad_params(dtype, d, p, workspace != nullptr, d != nullptr && d->upsample0 == 2)) return rc;
   if (d && d->B == 0) return 0;
   D3F_CHECK(dy && w_dgrad && dx0 && (d->C1 == 0 || dx1), "conv_backward_data: null argument");
   p.src0 = dy; p.w = w_dgrad; p.out0 = dx0; p.out1 = dx1; p.acc0 = acc0; p.acc1 = acc1;

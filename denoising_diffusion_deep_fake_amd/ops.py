@@ -111,15 +111,21 @@ def conv_upsample_folded(d, dtype=F32):
     return bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))
 
 
-def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False, splitk=False):
+def conv_backward_data(d, dy, wd, dtype=F32, dx0=None, dx1=None, acc0=False, acc1=False, splitk=False, summed=None):
     """(dx0, dx1): gradients of src0 and src1.  For an up-sampled src0 (d.upsample0) dx0 is the gradient of the
     LOW-resolution tensor [B, H/2, W/2, C0] -- written directly by the folded 4x4 stride-2 kernel where the layer
-    qualifies, else reduced here from the full-resolution gradient of the up-sampled operand."""
+    qualifies, else reduced here from the full-resolution gradient of the up-sampled operand.  summed=False keeps the
+    full-resolution + d3f_upsample2x_backward route also where the launch could sum the 2x2 blocks itself."""
     dev = _dev(dy)
     ws = _conv_ws(d, dtype, 1, dev, splitk)
     folded = bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_folded(dtype, C.byref(d)))
-    # ... or summed 2x2 in the launch's own epilogue (the patch form of the bf16 16 -> 32 layer): low resolution too
-    folded = folded or (bool(d.upsample0) and bool(_lib.lib().d3f_conv_upsample_summed(dtype, C.byref(d))))
+    # ... or summed 2x2 in the launch's own epilogue (the patch form of the bf16 16 -> 32 layer): low resolution too.
+    # That form is opt-in (upsample0 = 2 in the descriptor): a C caller on the full-resolution contract keeps it.
+    if bool(d.upsample0) and not folded and summed is not False and \
+            bool(_lib.lib().d3f_conv_upsample_summed(dtype, C.byref(d))):
+        d = ConvDesc(*[getattr(d, n) for n, _ in ConvDesc._fields_])
+        d.upsample0 = 2
+        folded = True
     low = (d.B, d.H // 2, d.W // 2, d.C0)
     if d.upsample0 and not folded:
         if acc0 or dx0 is not None:

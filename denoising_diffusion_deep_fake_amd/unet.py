@@ -236,6 +236,10 @@ class _UnetFunction(torch.autograd.Function):
         return (None, None, None, None)  # every .grad was set by _run_backward (views of the flat gradient buffer)
 
 
+def _views_unverified(module, incompatible_keys):
+    module._rt["verified"] = False
+
+
 class Unet(nn.Module):
     def __init__(self, encoder_name="resnet34", encoder_weights=None, in_channels=3, classes=3,
                  activation=None, compute_dtype="f32"):
@@ -258,6 +262,7 @@ class Unet(nn.Module):
         nn.init.xavier_uniform_(self.segmentation_head[0].weight)
         nn.init.constant_(self.segmentation_head[0].bias, 0)
         self._init_runtime_state()
+        self.register_load_state_dict_post_hook(_views_unverified)  # (load_state_dict(assign=True) swaps Parameter objects)
 
     # -- runtime state that must not be deep-copied / pickled ------------------------------------
     def _init_runtime_state(self):
@@ -309,9 +314,17 @@ class Unet(nn.Module):
     def _ensure_flat(self, device):
         """(re)establish: every parameter / BN buffer is a view into the flat device buffers."""
         rt = self._rt
+        flat = rt["flat"]
+        if rt.get("verified") and flat is not None and flat.device == device:
+            # fast path (every forward comes through here: the full walk below costs ~0.9 ms of host time): the views were
+            # verified once and nothing that re-homes parameter storage has run since -- nn.Module._apply (.to / .cuda /
+            # .float ...) clears the flag; the first and last parameter and statistics views are still re-checked
+            ps, bn = rt["params"], rt["flat_bn"]
+            if ps[0].data_ptr() == flat.data_ptr() and ps[-1].data_ptr() + 4 * ps[-1].numel() == flat.data_ptr() + 4 * flat.numel() \
+                    and rt["bn_first"].running_mean.data_ptr() == bn.data_ptr():
+                return
         ptable, btable, nparam, nbn = self._table()
         named = dict(self.named_parameters())
-        flat = rt["flat"]
         ok = flat is not None and flat.device == device
         if ok:
             base = flat.data_ptr()
@@ -328,6 +341,8 @@ class Unet(nn.Module):
                     ok = False
                     break
         if ok:
+            rt["verified"] = True
+            rt["bn_first"] = dict(self.named_modules())[btable[0][0]]
             return
         flat = torch.empty(nparam, dtype=torch.float32, device=device)
         flat_bn = torch.empty(nbn, dtype=torch.float32, device=device)
@@ -350,7 +365,7 @@ class Unet(nn.Module):
                 flat_nbt[i] = bn.num_batches_tracked.to(device)
                 bn.num_batches_tracked = flat_nbt[i]
         rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, grad_views=None, dirty=True,
-                  params=[named[name] for name, _, _ in ptable])
+                  params=[named[name] for name, _, _ in ptable], verified=True, bn_first=mods[btable[0][0]])
         for p in named.values():
             p.grad = None
 
@@ -365,6 +380,12 @@ class Unet(nn.Module):
             self._rt["engines"] = {}
             self._rt.pop("last_engine", None)
         return self
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .cpu() / .float() ...: torch replaces every parameter's storage -- the flat views are gone
+        out = super()._apply(fn, *args, **kwargs)
+        self._rt["verified"] = False
+        return out
 
     def mark_params_changed(self):
         """call after writing the flat parameter buffer behind autograd's back (fused Adam / EMA)."""

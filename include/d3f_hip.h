@@ -210,7 +210,8 @@ int d3f_unet_export_shape(d3f_unet_t h, const char* name, int32_t dims[3]);
 typedef struct d3f_conv_desc {
   int32_t B, H, W;    /* extent of the conv input (after the optional x2 up-sampling of src0) */
   int32_t C0, C1;     /* channels of src0 and of the concatenated src1 (0: none); padded to 4 (f32) / 8 (bf16) */
-  int32_t upsample0;  /* 1: src0 is [B][H/2][W/2][C0], read through nearest x2 up-sampling */
+  int32_t upsample0;  /* 1: src0 is [B][H/2][W/2][C0], read through nearest x2 up-sampling; 2: the same, and
+                       * d3f_conv_backward_data may hand back dx0 at that LOW resolution (see there) */
   int32_t Cout, KH, KW, stride, pad;
   int32_t CinReal;    /* unpadded input channels of the f32 master weight [Cout][CinReal][KH][KW] */
 } d3f_conv_desc;
@@ -248,10 +249,11 @@ int d3f_conv_winograd_forward(const d3f_conv_desc* d, const void* src0, const vo
  * overwriting.  With upsample0, dx0 is the gradient of the LOW-resolution source [B][H/2][W/2][C0] when the layer
  * runs with the up-sampling folded into pre-summed weights (d3f_conv_upsample_folded() == 1: 3x3, stride 1, pad 1,
  * whole k-tiles per tap -- every decoder layer of the network), else the full-resolution [B][H][W][C0] gradient of
- * the up-sampled operand, to be reduced with d3f_upsample2x_backward -- unless d3f_conv_upsample_summed() == 1 (bf16
- * storage, 16 -> 32 channels, one source: decoder.blocks.4.conv1 of smp's UnetDecoder, the F.interpolate + conv2d pair
- * under d3f/train_denoiser/lit_module.py:117): the launch then sums the 2x2 blocks in its epilogue and dx0 is the
- * LOW-resolution gradient as in the folded case. */
+ * the up-sampled operand, to be reduced with d3f_upsample2x_backward.  Opt-in third form: a caller that sets
+ * upsample0 = 2 in the descriptor AND finds d3f_conv_upsample_summed() == 1 (bf16 storage, 16 -> 32 channels, one source:
+ * decoder.blocks.4.conv1 of smp's UnetDecoder, the F.interpolate + conv2d pair under d3f/train_denoiser/lit_module.py:117)
+ * gets the 2x2 blocks summed in the launch's epilogue: dx0 is the LOW-resolution gradient as in the folded case.  With
+ * upsample0 = 1 that layer keeps the full-resolution contract. */
 int d3f_conv_upsample_folded(int dtype, const d3f_conv_desc* d);
 int d3f_conv_upsample_summed(int dtype, const d3f_conv_desc* d);
 int d3f_conv_backward_data(int dtype, const d3f_conv_desc* d, const void* dy, const void* w_dgrad,

@@ -90,6 +90,11 @@ def test_conv_bf16(case):
     assert rel_l2(to_nchw(dx0.float().cpu()), want0) < 4e-3
     if C1:
         assert rel_l2(to_nchw(dx1.float().cpu()), xin.grad[:, C0:]) < 4e-3
+    if up and not C1 and not ops.conv_upsample_folded(d, ops.BF16):
+        # the same gradient on the full-resolution contract (descriptor upsample0 = 1: what a C caller that never asked
+        # for the 2x2-summed epilogue gets) -- d3f_conv_backward_data + d3f_upsample2x_backward
+        dx0_full, _ = ops.conv_backward_data(d, dyh, wd, dtype=ops.BF16, splitk=True, summed=False)
+        assert dx0_full.shape == dx0.shape and rel_l2(to_nchw(dx0_full.float().cpu()), want0) < 4e-3
     dw = ops.conv_backward_weight(d, dyh, s0, s1, dtype=ops.BF16)
     assert rel_l2(dw.cpu(), wr.grad) < 1e-5
 
@@ -310,8 +315,9 @@ BF16_BWD_TOL_BN = 7.7e-3
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("shape", [(4, 64, 64), (16, 128, 128), (16, 256, 256)],
-                         ids=["4x64x64", "config1_16x128x128", "headline_16x256x256"])
+@pytest.mark.parametrize("shape", [(4, 64, 64), (16, 128, 128), (16, 256, 256), (8, 256, 256, "pair"), (2, 448, 448)],
+                         ids=["4x64x64", "config1_16x128x128", "headline_16x256x256", "paired_8x256x256_network_1_of_a_pair",
+                              "authors_2x448x448"])
 def test_bf16_every_layer_backward_teacher_forced(shape):
     """The bf16 engine plan's BACKWARD pass tensor by tensor (it differs from the fp32 plan: at 16 x 256 x 256 the
     patch-resident conv_pres_kernel for 35 data gradients, the bf16 patch kernels incl. the 2x2-summed data gradient of
@@ -324,35 +330,59 @@ def test_bf16_every_layer_backward_teacher_forced(shape):
     ":da" and each of the 143 parameter gradients therefore compares ONE layer's data gradient + BatchNorm backward +
     weight gradient on identical operands: what is left is bf16 rounding of the stored dy / y / packed weights
     (2^-9 per element).  A missed accumulate, a wrong bucket edge, tap or slab is O(1e-1 .. 1).
-    Replaces autograd through /root/reference/d3f/train_denoiser/lit_module.py:117-119 in the bf16 mode (BASELINE configs[2])."""
+    Replaces autograd through /root/reference/d3f/train_denoiser/lit_module.py:117-119 in the bf16 mode (BASELINE configs[2]).
+    (8, 256, 256, "pair"): BASELINE configs[3]'s per-net batch the way the trainer runs it since round 6 -- TWO bf16 networks
+    stepped as one set of launches (UnetPair, d3f/train_deep_fake/lit_module.py:142-181); the tensors checked are those of
+    network 1, the one whose workgroups add the second network's offsets to every pointer.  (2, 448, 448): the authors'
+    resolution, ragged against every tile."""
     import gc
 
     import oracle
     from oracle.pinned import teacher_forced_backward, unit_names
-    from denoising_diffusion_deep_fake_amd import Unet, ops
-    B, H, W = shape
-    torch.manual_seed(3)
-    ref = oracle.Unet("resnet34", None, 3, 3, None).train()
-    with torch.no_grad():
-        for m in ref.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.weight.uniform_(0.5, 1.5)
-                m.bias.normal_(0, 0.1)
-        ref.segmentation_head[0].bias.normal_(0, 0.1)
-    net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16")
-    net.load_state_dict(ref.state_dict())
-    net = net.cuda().train()
+    from denoising_diffusion_deep_fake_amd import Unet, UnetPair, ops
+    B, H, W = shape[:3]
+    paired = len(shape) > 3
+
+    def oracle_net(seed):
+        torch.manual_seed(seed)
+        ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+        with torch.no_grad():
+            for m in ref.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.1)
+            ref.segmentation_head[0].bias.normal_(0, 0.1)
+        return ref
+
+    def hip_net(ref):
+        net = Unet("resnet34", None, 3, 3, None, compute_dtype="bf16")
+        net.load_state_dict(ref.state_dict())
+        return net.cuda().train()
+    ref = oracle_net(3)
+    net = hip_net(ref)
     x = oracle.synthetic_face_crops(B, (H, W), seed=21)
-    pred = net(x.cuda())
-    _, gout = ops.mse_ssim_loss(pred.detach(), oracle.synthetic_face_crops(B, (H, W), seed=22).cuda())
-    pred.backward(gout)
+    tgt = oracle.synthetic_face_crops(B, (H, W), seed=22).cuda()
     names = unit_names()
+    if paired:  # network 0: another network on another batch; `ref` / `net` / `x` are network 1
+        other = hip_net(oracle_net(4))
+        pair = UnetPair(other, net)
+        p0, pred = pair(oracle.synthetic_face_crops(B, (H, W), seed=31).cuda(), x.cuda())
+        _, gout = ops.mse_ssim_loss(pred.detach(), tgt)
+        torch.autograd.backward([p0, pred], [ops.mse_ssim_loss(p0.detach(), tgt)[1], gout])
+        export = lambda n: pair.export_activation(1, n)  # noqa: E731
+    else:
+        pred = net(x.cuda())
+        _, gout = ops.mse_ssim_loss(pred.detach(), tgt)
+        pred.backward(gout)
+        export = net.export_activation
     chan = {n: dict(ref.named_modules())[n].out_channels for n in names}
-    hip_a = {n: net.export_activation(n + ":a").cpu()[:, :chan[n]] for n in names}
-    hip_da = {n: net.export_activation(n + ":da").cpu()[:, :chan[n]] for n in names}
+    hip_a = {n: export(n + ":a").cpu()[:, :chan[n]] for n in names}
+    hip_da = {n: export(n + ":da").cpu()[:, :chan[n]] for n in names}
     hip_grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
     gout = gout.cpu()
-    del net, pred
+    del net, pred, export
+    if paired:
+        del pair, other, p0
     torch.cuda.empty_cache()
     gc.collect()
     dact, grads = teacher_forced_backward(ref, x, gout, hip_a, hip_da, names)

@@ -191,6 +191,105 @@ def test_paired_domain_step_full_size():
     assert torch.isfinite(ga1).all() and torch.isfinite(gb1).all() and not torch.equal(ga1, gb1)
 
 
+def test_paired_domain_fused_step_full_size_equals_the_sequential_loop():
+    """BASELINE configs[3] as the trainer runs it (round 6): the denoise-mode batch of 2 x 8 images at 256x256 through
+    trainer.optimizer_steps' FUSED route (both nets' forward / backward as one set of launches, UnetPair) -- two batches,
+    both Adam steps each -- against Lightning's one-after-the-other loop on the same kernel choices (`pair_plan`): losses,
+    both flat gradients and both updated parameter buffers bit-identical, and the fused route run to run reproducible
+    (reference: d3f/train_deep_fake/lit_module.py:142-181)."""
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    from denoising_diffusion_deep_fake_amd.trainer import optimizer_steps
+
+    def run(**kw):
+        torch.manual_seed(3)
+        lit = LitModule(mode="denoise", batch_size=8, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=1,
+                        cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
+                        noise_exponential_sampling_lambda=3, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
+                        std_b=[0.5] * 3, synthetic=True, image_size=256, augment=False, **kw).cuda().train()
+        opts, _ = lit.configure_optimizers()
+        opt_params = [[p for g in o.param_groups for p in g["params"]] for o in opts]
+        batch = {k: {"image": synthetic_face_crops(8, 256, seed=7 + i, device="cuda"), "index": None}
+                 for i, k in enumerate("ab")}
+        torch.manual_seed(50)
+        losses = []
+        for it in range(2):
+            optimizer_steps(lit, opts, opt_params, batch, it, True, None)
+            losses += [float(lit._logged["loss_denoise/train_a"]), float(lit._logged["loss_denoise/train_b"])]
+        return (losses, lit.model_a.flat_grads.clone(), lit.model_b.flat_grads.clone(), lit.model_a.flat_params.clone(),
+                lit.model_b.flat_params.clone(), lit._pair is not None)
+    f1, f2, s = run(), run(), run(pair_fused=False, pair_plan=True)
+    assert f1[5] and f2[5] and not s[5]
+    for k in range(5):
+        assert (f1[k] == f2[k]) if k == 0 else torch.equal(f1[k], f2[k]), ("fused run to run", k)
+        assert (f1[k] == s[k]) if k == 0 else torch.equal(f1[k], s[k]), ("fused vs sequential", k)
+    assert all(l == l for l in f1[0]) and not torch.equal(f1[1], f1[2])
+
+
+@pytest.mark.timeout(900)
+def test_swap_step_full_size_against_the_oracle():
+    """The reference's 200-epoch phase at BASELINE configs[3]'s size (`mode: "swap"`, 8 x 256 x 256 per domain, both
+    optimizer indices; d3f/train_deep_fake/lit_module.py:183-206 and swap_config.yml): per index the EMA teacher of the
+    OTHER net is updated and renders the fake under no_grad with train-mode BatchNorm, the explicit noise draws blend it,
+    the student denoises it -- `loss_swap`, `swap_difference` and the student's flat gradient against oracle.swap_step in
+    float64 (index 0 also against the CPU-fp32 oracle as the yardstick), and index 1 sees net a AFTER its Adam step through
+    its teacher."""
+    import numpy as np
+
+    import oracle
+    from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
+    from util import rel_l2
+    torch.manual_seed(5)
+    lam = 8
+    lit = LitModule(mode="swap", batch_size=8, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=1,
+                    cosine_scheduler_max_epoch=200, num_workers=0, encoder_name="resnet34",
+                    noise_exponential_sampling_lambda=lam, mean_a=[0.5] * 3, std_a=[0.5] * 3, mean_b=[0.5] * 3,
+                    std_b=[0.5] * 3, synthetic=True, image_size=256, ema_beta=0.9999, ema_update_every=1,
+                    augment=False).cuda().train()
+    opts, _ = lit.configure_optimizers()
+    xs = {"a": oracle.synthetic_face_crops(8, 256, seed=41), "b": oracle.synthetic_face_crops(8, 256, seed=42)}
+    batch = {k: {"image": v.cuda(), "index": None} for k, v in xs.items()}
+    crit = oracle.MseStructuralSimilarityLoss(-1.0, 1.0)
+
+    def replica(model, dtype):
+        ref = oracle.Unet("resnet34", None, 3, 3, None).train()
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        return ref.to(dtype)
+
+    def draws(seed, shape):
+        torch.manual_seed(seed)
+        noise = torch.randn(shape, device="cuda")
+        y = torch.rand(size=(shape[0], 1, 1, 1), device="cuda")
+        c = 1 / np.exp(lam)
+        return noise.cpu(), 1 / lam * torch.log(1 / (y.reshape(-1).cpu() * (1 - c) + c))
+
+    for oi, (name, student, other) in enumerate((("a", lit.model_a, lit.model_b), ("b", lit.model_b, lit.model_a))):
+        out = {}
+        for dtype in ((torch.float32, torch.float64) if oi == 0 else (torch.float64,)):
+            st = replica(student, dtype)
+            teacher = oracle.EMA(replica(other, dtype), beta=0.9999, update_every=1)   # first update(): a copy of `other`
+            noise, r = draws(99 + oi, xs[name].shape)
+            loss, diff, _, _ = oracle.swap_step(xs[name].to(dtype), st, teacher, crit, noise.to(dtype), r.to(dtype))
+            loss.backward()
+            out[dtype] = (loss.item(), diff.item(), torch.cat([p.grad.reshape(-1) for p in st.parameters()]))
+        torch.manual_seed(99 + oi)
+        opts[oi].zero_grad(set_to_none=True)
+        loss = lit.training_step(batch, 0, oi)
+        loss.backward()
+        l64, d64, g64 = out[torch.float64]
+        l32, d32, g32 = out.get(torch.float32, (None, None, None))
+        assert abs(loss.item() - l64) < (max(4 * abs(l32 - l64), 5e-6) if l32 is not None else 2e-5), (oi, loss.item(), l32, l64)
+        sd = float(lit._logged[f"swap_difference/{name}"])
+        assert abs(sd - d64) < 1e-5 * d64, (oi, sd, d64)
+        e_hip = rel_l2(student.flat_grads, g64)
+        e_cpu = rel_l2(g32, g64) if g32 is not None else None
+        # (unpinned ReLU / max-pool masks: the floor of two fp32 evaluations; the 2e-4 mask-pinned gate on every tensor at
+        # this size is tests/test_gpu_parity_layers.py)
+        assert e_hip < 5e-2 and (e_cpu is None or e_hip < max(10 * e_cpu, 2e-5)), (oi, e_hip, e_cpu)
+        opts[oi].step()
+    assert lit.ema_model_a._host_step == 1 and lit.ema_model_b._host_step == 1
+
+
 def test_eval_fused_epilogue_matches_train_path_apply_at_b64():
     """BASELINE config 4's shape (B=64, 256x256, eval mode): the eval kernels fold BatchNorm (+ residual + ReLU) into
     the conv epilogue and pick other tiles / split-K factors than the small tests.  With the running statistics set to
