@@ -31,7 +31,7 @@ constexpr int BNF_MAX_ROWS = 1024;  // partial rows a workgroup is asked to redu
 #endif  // partial rows a workgroup is asked to reduce (x 256 B)
 
 bool bn_fused_finalize_ok(int dtype, int stat_rows, int C) {
-  static const bool off = getenv("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
+  static const bool off = prof_knob("D3F_NO_BN_FUSED_FINALIZE") != nullptr;  // debugging knob: separate launches
   return !off && (dtype == D3F_F32 || dtype == D3F_BF16) && (C % BNF_SC) == 0 && stat_rows >= 1 && stat_rows <= BNF_MAX_ROWS;
 }
 

@@ -26,6 +26,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 namespace d3f {
 
+// Debugging / sweep knobs whose verdict is recorded (profiles/README.md) exist only in profiling builds
+// (make EXTRA=-DD3F_PROFILING, loaded through D3F_LIB): the shipped library does not read them.
+static inline const char* prof_knob(const char* name) {
+#ifdef D3F_PROFILING
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // thread-local error string (c_api.cpp)
 int set_error(int code, const char* fmt, ...);
 #define D3F_CHECK(cond, ...)                              \
@@ -225,8 +236,12 @@ struct ConvParams {
   int sum2;            // CONV_DGRAD request (set before the plan): store the 2x2 block sums of the gradient at HALF resolution
                        // (the gradient w.r.t. a source that was read through the nearest x2 up-sampling); kept only when
                        // a patch kernel takes the launch -- the plan clears it otherwise and the caller reduces itself
-  // (9 / 10 / 11: conv_pres_kernel for 64 / 128 / 256 channels, conv_pres.hip)
-  int patch;           // 1: runs as conv_patch_kernel, 2: conv_stem_kernel, 3: conv_patch_kernel on bf16 storage (conv_patch.hip; filled by plan)
+  // which kernel takes the launch (filled by the plan; THE table -- d3f_unet_plan_counts and the tests refer to it):
+  //   0 conv_igemm_kernel;  conv_patch.hip: 1 conv_patch_kernel fp32 (16 or 4 staged channels), 2 conv_stem_kernel,
+  //   3 conv_patch_kernel bf16 x 16 channels, 4 bf16 x 32 channels (32 / 64 filters), 5 bf16 x 32 behind the up-sampling,
+  //   6 bf16 x 8 source channels staged as 16 (the head's data gradient), 7 bf16 16 -> 32 with the 2x2-summed epilogue,
+  //   8 conv_stem_bf16_kernel;  conv_pres.hip: 9 / 10 / 11 / 12 conv_pres_kernel for 64 / 128 / 256 / 512 channels
+  int patch;
   // two networks in one launch (NetSplit): grid.z = nets * nz; a workgroup of net 1 shifts every pointer above by net_ws,
   // except out0 (net_out0: the NCHW prediction of CONV_HEAD_NCHW lives outside the workspace) and scale (net_scale: the
   // head's bias is a parameter).  plan_nets (set before the plan): the tile / split-K / patch-kernel choices count the
@@ -253,7 +268,7 @@ struct ConvTile {
 // Does conv(cat(upsample2x(x0), x1)) run with the up-sampling folded into pre-summed weights (ConvParams::par == 3
 // forward, 4x4 stride-2 data gradient)?  Needs whole k-tiles per tap in both sources.
 static inline bool upfold_applies(int dtype, int upsample0, int k, int stride, int pad, int C0, int C1) {
-  static const bool off = getenv("D3F_NO_UPFOLD") != nullptr;  // debugging knob: gather through the up-sampling
+  static const bool off = prof_knob("D3F_NO_UPFOLD") != nullptr;  // debugging knob: gather through the up-sampling
   const int bke = dtype == D3F_BF16 ? 64 : 32;
   return !off && upsample0 && k == 3 && stride == 1 && pad == 1 && C0 > 0 && (C0 % bke) == 0 && (C1 % bke) == 0;
 }

@@ -1565,7 +1565,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
 template <typename T, int BM, int BN, int WGM, int WGN, int MT, bool X3>
 static int launch_cfg(const ConvParams& p, bool smallc, hipStream_t stream) {
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splitk, (unsigned)(p.nz * nets_of(p.nets))), block(256);
-  static const bool no_fast = getenv("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
+  static const bool no_fast = prof_knob("D3F_NO_FAST_ADDR") != nullptr;  // debugging knob
   const bool fast = !no_fast && !smallc && p.C1 == 0 && p.shift0 == 0 && p.zi == 0 && p.KH * p.KW <= 32;
   if (p.par == 3)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, MT, false, 2, X3>), grid, block, 0, stream, p);

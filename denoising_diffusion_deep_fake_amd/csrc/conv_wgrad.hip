@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedu
 // (twice the L2 -> LDS staging per MFMA, r03)
 static int pick_wtile(const WgradParams& p) { return (p.Cout > 32 && p.C0 + p.C1 > 32) ? 64 : 32; }
 static bool patch_wgrad_off() {
-  static const bool off = getenv("D3F_NO_PATCH_WGRAD") != nullptr;  // debugging knob: the tap-parallel kernel everywhere
+  static const bool off = prof_knob("D3F_NO_PATCH_WGRAD") != nullptr;  // debugging knob: the tap-parallel kernel everywhere
   return off;
 }
 
@@ -523,7 +523,7 @@ int wgrad_patch_launch(const WgradParams& p, int variant, int dtype, hipStream_t
 // Does the weight gradient of conv(cat(upsample2x(src0), src1)) run as WG_CLASS + WG_SKIP passes?  The tap-parallel
 // kernel's 64x64 tile only (the narrow decoder layers keep the persistent patch kernel); C0 a whole number of ci tiles.
 bool wgrad_class_applies(const WgradParams& p, int dtype) {
-  static const bool off = getenv("D3F_NO_WGRAD_CLASS") != nullptr;  // debugging knob: nine taps through the up-sampling
+  static const bool off = prof_knob("D3F_NO_WGRAD_CLASS") != nullptr;  // debugging knob: nine taps through the up-sampling
   if (off || !p.shift0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
   if (p.Ho != p.Hv || p.Wo != p.Wv || p.H0s * 2 != p.Hv || p.W0s * 2 != p.Wv) return false;
   if (!patch_wgrad_off()) {
@@ -578,7 +578,7 @@ int wgrad_plan(WgradParams& p, int dtype) {
   p.tiles_ci = cdiv(p.slab_cin, t);
   const long base = (long)p.tiles_co * p.tiles_ci * p.slab_taps;
   const int total_chunks = cdiv(p.Mi, KP);
-  static const long target_env = getenv("D3F_WGRAD_TARGET") ? atol(getenv("D3F_WGRAD_TARGET")) : 0;  // sweep knob
+  static const long target_env = prof_knob("D3F_WGRAD_TARGET") ? atol(prof_knob("D3F_WGRAD_TARGET")) : 0;  // sweep knob
   // fp32: ~3.6 workgroups per CU (r02_ao/ap/aq sweep of 640 ... 1280: 896-960 best, 1024 +1 %, 1280 +2 %).  bf16 storage
   // (round 5 sweep, profiles/README.md: 232 ... 1856): the launches are latency-bound, not MFMA-bound, and the stream is as
   // long as the chain in the backward window -- 1152 is 1.2 % faster per step than 928, 640 1.4 % slower, 1856 1.8 % slower

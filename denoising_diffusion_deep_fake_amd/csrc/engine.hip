@@ -48,16 +48,24 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
   }
   if (threadIdx.x == 0) partial[((long)c * nb + b) * CS_PP + seg] = red[0];
 }
-__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int C, int n,
-                                         float* __restrict__ out, long net_ws, long net_grad) {
+// one workgroup per channel: thread t sums partial[c][t], [t + 256], ... in f64, the 256 sums are added pairwise in a fixed
+// tree (reproducible).  (One THREAD per channel walked its 256 partials as dependent loads: 54 us for three channels.)
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ partial, int C, int n,
+                                                                float* __restrict__ out, long net_ws, long net_grad) {
   if (blockIdx.z != 0) {  // two networks in one launch: the head's bias gradient lands in net 1's flat gradient
     net_shift(partial, net_ws); net_shift(out, net_grad);
   }
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[256];
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)partial[(long)c * n + i];
-  out[c] = (float)s;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[(long)c * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)red[0];
 }
 size_t channel_sum_partial_floats(int B, int C) { return (size_t)B * C * CS_PP; }
 int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partial, float* out,
@@ -67,7 +75,7 @@ int channel_sum_nchw_launch(const float* x, int B, int C, long HW, float* partia
   hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(CS_PP, C, B * nv.nets), dim3(256), 0, stream, x, C, HW, partial, B,
                      nv.in, nv.ws);
   D3F_HIP(hipGetLastError());
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 64), 1, nv.nets), dim3(64), 0, stream, partial, C, B * CS_PP, out,
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(C, 1, nv.nets), dim3(256), 0, stream, partial, C, B * CS_PP, out,
                      nv.ws, nv.grad);
   D3F_HIP(hipGetLastError());
   return 0;
@@ -455,7 +463,7 @@ int UnetEngine::build(const char* encoder, int in_channels_, int classes_, int B
   // gradient also emits the (dbeta, dgamma) partial sums of the unit that consumes it -- when that unit is the very
   // next op (bnpart is one stream-ordered scratch).  The producer may accumulate (it sums first, then reduces the
   // final values); a consumer with a residual add takes its ReLU mask from its activation instead of from y.
-  static const bool no_fused_reduce = getenv("D3F_NO_FUSED_BN_REDUCE") != nullptr;  // debugging knob: separate reduce launches
+  static const bool no_fused_reduce = prof_knob("D3F_NO_FUSED_BN_REDUCE") != nullptr;  // debugging knob: separate reduce launches
   if (!no_fused_reduce) {
     auto writes = [&](const BwdOp& o, int gid) {
       if (o.kind == BW_UNIT || o.kind == BW_HEAD) {
@@ -769,6 +777,19 @@ int UnetEngine::forward_body(const float* params_, float* bnstats, float* out, c
           return set_error(rc, "BatchNorm statistics all-reduce failed in the forward pass (%s)", u.bn_name.c_str());
       }
       const long count = rows * (sync ? bn_sync_world_ : 1);
+#ifdef D3F_PROFILING
+      // timing-only ablation (wrong activations; profiling builds only): D3F_ABLATE_FWD_BN=1 replaces the streaming
+      // BatchNorm + ReLU pass of every layer WITHOUT a residual add by the coefficient-only finalize launch -- the ceiling
+      // of "apply the two coefficients in the consumer's patch staging instead"  before any consumer cost
+      static const bool abl_fbn = getenv("D3F_ABLATE_FWD_BN") != nullptr;
+      if (abl_fbn && !sync && u.apply && u.res_tensor < 0 && ds == nullptr) {
+        if (int rc = bn_finalize_launch(p.stats, p.stat_rows, u.Cout, u.CoutPad, count, params_ + u.g_off, params_ + u.b_off,
+                                        1e-5f, 0.1f, bnstats + u.rm_off, bnstats + u.rv_off, coef_ptr(ws, u, 0),
+                                        coef_ptr(ws, u, 1), coef_ptr(ws, u, 2), coef_ptr(ws, u, 3), s, ns))
+          return rc;
+        continue;
+      }
+#endif
       if (!sync && u.apply && bn_fused_finalize_ok(dtype, p.stat_rows, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip): one launch instead of two
         if (int rc = bn_finalize_apply_launch(dtype, p.stats, p.stat_rows, u.Cout, u.CoutPad, rows, params_ + u.g_off,
@@ -1136,6 +1157,14 @@ int UnetEngine::backward(const float* params_, const float* dout, float* grads, 
                                          op.dres == -1 ? nullptr : G(op.dres), op.dres_acc ? 1 : 0, rows,
                                          u.Cout, s, msc, msf))
           return rc;
+#ifdef D3F_PROFILING
+      } else if (!skip_b && getenv("D3F_ABLATE_BWD_BN") != nullptr && op.dres == -1 && from_y) {
+        // timing-only ablation (wrong gradients): the backward streaming pass of the layers without a residual replaced by
+        // the coefficient-only finalize launch -- the ceiling of VERDICT r5 item 4b (dy made in the data gradient's staging)
+        if (int rc = bn_bwd_finalize_launch(bnpart, nb, u.Cout, rows, params_ + u.g_off, invstd, grads + u.g_off,
+                                            grads + u.b_off, 0, k, s, ns))
+          return rc;
+#endif
       } else if (!skip_b && bn_fused_finalize_ok(dtype, nb, u.Cout)) {
         // finalize folded into the streaming pass (bn_fused.hip)
         if (int rc = bn_bwd_finalize_apply_launch(dtype, bnpart, nb, u.Cout, rows, params_ + u.g_off, mean, invstd,

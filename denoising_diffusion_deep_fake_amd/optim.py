@@ -26,8 +26,10 @@ class FusedAdam(torch.optim.Optimizer):
         layer4, the decoder and the head already hold their updated values when backward() returns; .grad is complete
         and untouched as always -- but EDITING .grad between backward() and step() (clip_grad_norm_ / Lightning's
         gradient_clip_val, GradScaler.unscale_, hooks that rescale gradients) cannot reach the 94 % of the parameters
-        whose update already ran: step() detects in-place edits of the flat gradient buffer (its version counter) and
-        RAISES instead of applying them to the last bucket only; use overlap_tail=False with any such step.  A data-parallel reducer, or gradients that do not land in the flat buffer directly
+        whose update already ran: step() detects in-place TORCH operations on the flat gradient buffer or its .grad views
+        (the buffer's autograd version counter) and RAISES instead of applying them to the last bucket only; writes that
+        bypass torch's bookkeeping (raw-pointer kernels such as this package's ops.* on .grad, `.data` tricks) are NOT
+        seen -- use overlap_tail=False with any step that edits gradients.  A data-parallel reducer, or gradients that do not land in the flat buffer directly
         (.grad not None before backward: zero_grad(set_to_none=False)), switch the early part off by themselves (the
         whole update then runs in step() as without the flag); a second backward() before step() (gradient accumulation),
         changed hyper-parameters or cleared gradients between backward() and step() raise in step()."""

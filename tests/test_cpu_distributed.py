@@ -229,7 +229,9 @@ def test_gradient_bucket_groups():
     assert g(2, 4) == [(0, 3), (3, 4)]
     assert g(1, 4) == [(0, 4)]
     assert g([(0, 3), (3, 4)], 4) == [(0, 3), (3, 4)]
-    for bad in (3, [(0, 2)], [(0, 2), (3, 4)], [(1, 4)], [(0, 2), (2, 2), (2, 4)]):
+    import inspect
+    assert inspect.signature(Unet.set_grad_sync).parameters["buckets"].default == 2   # one default everywhere (DataParallel's)
+    for bad in (3, True, False, [(0, 2)], [(0, 2), (3, 4)], [(1, 4)], [(0, 2), (2, 2), (2, 4)]):
         with pytest.raises(D3FError):
             g(bad, 4)
 
