@@ -673,7 +673,7 @@ def pmc_from_file(name, key, args):
     if tag is None:
         return None, None
     path = None
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         cand = os.path.join(ROOT, "profiles", f"{rnd}_{tag}{name}")
         if os.path.exists(cand):
             path, name = cand, f"{rnd}_{tag}{name}"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round evidence, as two gpurun calls (each well inside 20 minutes):
-#   gpurun --timeout 1200 -- 'bash profiles/tools/end_of_round.sh counters r05 <git head>'
+#   gpurun --timeout 1200 -- 'bash profiles/tools/end_of_round.sh counters r06 <git head>'
 #   (copy gpurun_out/<tag>_*{traffic,hbm_kernels,mfma_util}.json into profiles/ and commit: bench.py attaches them by digest)
 #   gpurun --timeout 1200 -- 'bash profiles/tools/end_of_round.sh benches r05'
 # counters: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ counters, separate runs) for f32 and bf16 256x256,
@@ -31,6 +31,10 @@ else
   python bench.py --size 128 --dtype bf16 --no-cpu-baseline > $O/bench_128_bf16.json 2>/dev/null
   python bench.py --size 448 --batch 14 --no-cpu-baseline --no-alt > $O/bench_448.json 2>/dev/null
   python bench.py --workload deepfake > $O/workload_deepfake.json 2>/dev/null
+  python bench.py --workload deepfake --pair-fused off > $O/workload_deepfake_sequential.json 2>/dev/null
+  python bench.py --workload deepfake --dtype bf16 > $O/workload_deepfake_bf16.json 2>/dev/null
+  python bench.py --workload deepfake --mode swap > $O/workload_deepfake_swap.json 2>/dev/null
+  python bench.py --workload deepfake --mode swap --dtype bf16 > $O/workload_deepfake_swap_bf16.json 2>/dev/null
   python bench.py --workload sample50 --steps 3 --warmup 1 > $O/workload_sample50.json 2>/dev/null
   python bench.py --workload sample50 --dtype bf16 --steps 3 --warmup 1 > $O/workload_sample50_bf16.json 2>/dev/null
   python bench.py --workload predict > $O/workload_predict.json 2>/dev/null
