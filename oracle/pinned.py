@@ -9,7 +9,6 @@ __graft_entry__.smoke(); restates autograd through d3f/train_denoiser/lit_module
 """
 import copy
 
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -120,18 +119,14 @@ class TeacherForcedReLU(nn.Module):
         return out
 
 
-def teacher_forced_backward(ref, x, grad_out, activations, act_grads, names, conditioning=False):
+def teacher_forced_backward(ref, x, grad_out, activations, act_grads, names):
     """float64 copy of `ref` (train mode) with BOTH passes teacher-forced by another run: in front of every layer the
     forward is handed that run's activation (`activations[unit]`), ReLU / max-pool decisions are pinned to it, and in
     the backward pass the gradient w.r.t. every unit's activation is replaced by that run's (`act_grads[unit]`) after the
     oracle's own value was recorded.  Each recorded activation gradient and each parameter gradient is therefore ONE
     layer's data gradient + BatchNorm backward + weight gradient applied to the other run's operands (a block's
     downsample branch: two layers).  Returns ({unit: oracle d loss / d activation}, {parameter name: gradient});
-    restates autograd through d3f/train_denoiser/lit_module.py:117-119 for the bf16 engine plan.
-    conditioning=True adds a third result, {conv weight name: kappa}: a weight gradient is a sum over pixels of products
-    dy * x that largely CANCELS, kappa = || sqrt(sum_m (dy_m x_m)^2) || / || sum_m dy_m x_m || says by how much -- a relative
-    rounding error eps on every dy_m (bf16 storage: 2^-9 / sqrt(3) rms) shows up as ~ eps * kappa in the gradient, whatever
-    the kernel: the yardstick a storage-precision gate on a weight gradient has to be read against."""
+    restates autograd through d3f/train_denoiser/lit_module.py:117-119 for the bf16 engine plan."""
     model = copy.deepcopy(ref).double().train()
     acts = [activations[n] for n in names]
     gin = [act_grads[n] for n in names]
@@ -139,26 +134,9 @@ def teacher_forced_backward(ref, x, grad_out, activations, act_grads, names, con
     swap_relus(model, lambda: TeacherForcedReLU(acts, gin, recorded))
     _, idx = F.max_pool2d(activations["encoder.conv1"].float(), 3, 2, 1, return_indices=True)
     model.encoder.maxpool = PinnedMaxPool(idx)
-    rss, hooks = {}, []
-    if conditioning:
-        for name, mod in model.named_modules():
-            if isinstance(mod, nn.Conv2d):
-                def keep_input(m, inp):
-                    m._tf_x = inp[0].detach()
-
-                def root_sum_square(m, gin_, gout_, name=name):
-                    with torch.no_grad():  # sum_m (dy_m x_m)^2 per weight element = the weight gradient of the squared operands
-                        sq = torch.nn.grad.conv2d_weight(m._tf_x ** 2, m.weight.shape, gout_[0] ** 2, m.stride, m.padding)
-                        rss[name + ".weight"] = float(sq.sum().sqrt())
-                    del m._tf_x
-                hooks += [mod.register_forward_pre_hook(keep_input), mod.register_full_backward_hook(root_sum_square)]
     out = model(x.double())
     assert not acts and not gin and len(recorded) == len(names)
     out.backward(grad_out.double())
-    for h in hooks:
-        h.remove()
     dact = {n: slot["g"] for n, slot in zip(names, recorded) if "g" in slot}
     grads = {k: p.grad for k, p in model.named_parameters()}
-    if conditioning:
-        return dact, grads, {k: v / max(float(grads[k].norm()), 1e-300) for k, v in rss.items()}
     return dact, grads
