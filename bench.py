@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--pair-fused", default="auto", choices=["auto", "on", "off"],
                     help="--workload deepfake, denoise mode: the two nets' steps as ONE set of launches (trainer.optimizer_steps "
                          "takes the fused route when the module offers it); off = Lightning's one-after-the-other loop")
+    ap.add_argument("--pair-plan", default="off", choices=["on", "off"],
+                    help="--workload deepfake: every network plans its kernels as for a UnetPair (hparam pair_plan: the "
+                         "tile / split-K / slab choices of a 16-image batch on 8-image launches) -- the A/B of the plan "
+                         "heuristics at 8 images per launch")
     ap.add_argument("--graph-step", default="off", choices=["on", "off"],
                     help="on: the whole optimiser step replayed from one captured hipGraph (graph_step.py; single GPU).  "
                          "Bit-identical to the eager step, and SLOWER on this ROCm (measured r03: bf16 4.6 -> 10.9 ms, "
@@ -458,7 +462,7 @@ def extra_workload(args):
                         cosine_scheduler_max_epoch=50, num_workers=0, encoder_name="resnet34",
                         noise_exponential_sampling_lambda=8 if swap else 3, mean_a=[0.5] * 3, std_a=[0.5] * 3,
                         mean_b=[0.5] * 3, std_b=[0.5] * 3, synthetic=True, image_size=args.size, precision=args.dtype,
-                        ema_beta=0.9999, ema_update_every=1, augment=False,
+                        ema_beta=0.9999, ema_update_every=1, augment=False, pair_plan=args.pair_plan == "on",
                         pair_fused={"auto": None, "on": True, "off": False}[args.pair_fused]).to(dev).train()
         opts, _ = lit.configure_optimizers()
         if swap:

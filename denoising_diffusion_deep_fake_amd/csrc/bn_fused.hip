@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
 // bf16 4.09 / 4.09 / 4.12 / 4.18 at 384 / 512 / 768 / 1024 -- unchanged optimum; 512 / 768 / 1024 only for the tensors of 32 MB
 // and more (stem, decoder block 3): 7.89 / 7.91 / 7.90 against 7.87 / 7.89 -- no gain either)
 static long rows_per_block_for(long rows, int slabs, int dtype, int plan_nets) {
-  const long wgs = (dtype == D3F_F32 ? 256 : 512) / nets_of(plan_nets);  // (two networks in one launch share the count)
+  const long wgs = (dtype == D3F_F32 ? 256 : 512) / plan_nets_for(plan_nets, 64);  // (two networks in one launch share the count)
   long rb = std::max(1L, wgs / slabs);
   long rpb = (rows + rb - 1) / rb;
   rpb = (rpb + 31) / 32 * 32;

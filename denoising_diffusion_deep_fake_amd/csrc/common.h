@@ -131,6 +131,13 @@ struct NetSplit {
   long out;   // NCHW boundary output (the forward's prediction)
 };
 static inline int nets_of(int n) { return n > 1 ? n : 1; }
+// plan_nets as one heuristic sees it.  Profiling builds only: D3F_PLAN_MASK=<bits> applies plan_nets to the heuristics whose
+// bit is set and 1 to the others (1 tile choice, 2 split-K, 4 patch-resident conv, 8 Winograd, 16 weight-gradient slabs,
+// 32 persistent weight-gradient grids, 64 BatchNorm row blocks) -- which of the pair's choices pays on 8-image launches
+static inline int plan_nets_for(int plan_nets, int bit) {
+  static const int mask = prof_knob("D3F_PLAN_MASK") ? atoi(prof_knob("D3F_PLAN_MASK")) : -1;
+  return (mask & bit) ? nets_of(plan_nets) : 1;
+}
 static inline NetSplit net_split_or_single(const NetSplit* ns) {
   NetSplit one{};
   one.nets = 1;

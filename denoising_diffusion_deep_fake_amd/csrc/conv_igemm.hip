@@ -1452,7 +1452,7 @@ static ConvTile pick_tile(const ConvParams& p, bool x3, bool bf16 = false) {
   // prefer the biggest tile that still gives >= 2 blocks per CU; small problems fall to 64x64
   const long M = p.M;
   const int nz = (p.par == 1 || p.par == 3) ? 4 : 1;  // output-parity classes share the launch
-  const int pn = nets_of(p.plan_nets);  // two networks share the launch: their workgroups count together
+  const int pn = plan_nets_for(p.plan_nets, 1);  // two networks share the launch: their workgroups count together
   auto blocks = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(co, bn) * nz * pn; };
   if (co % 128 == 0 && blocks(128, 128) >= 512) return {128, 128};
   if (blocks(128, 64) >= 512) return {128, 64};
@@ -1540,7 +1540,7 @@ int conv_igemm_plan(ConvParams& p, int dtype, bool allow_splitk) {
   p.splitk = 1;
   p.stat_rows = p.nz * p.tiles_m;
   // deep layers: M x Cout gives too few workgroups to fill 256 CUs -> cut the K loop
-  const long base = (long)p.tiles_m * p.tiles_n * p.nz * nets_of(p.plan_nets);
+  const long base = (long)p.tiles_m * p.tiles_n * p.nz * plan_nets_for(p.plan_nets, 2);
   const int nk = p.Kpad / bke;
   const int vc = p.Cout / 4;
   static const bool no_splitk = getenv("D3F_NO_SPLITK") != nullptr;  // debugging knob

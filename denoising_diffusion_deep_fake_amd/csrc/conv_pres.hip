@@ -346,13 +346,17 @@ bool conv_pres_applies(const ConvParams& p, int dtype) {
     return false;
   const PresPick k = pres_pick(p);
   if (!k.id || (p.Cout % k.BN) != 0 || (p.Ho % (k.BM / k.TW)) != 0) return false;
-  const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN) * nets_of(p.plan_nets);
+  const long wgs = (long)p.B * (p.Ho / (k.BM / k.TW)) * (p.Wo / k.TW) * (p.Cout / k.BN) * plan_nets_for(p.plan_nets, 4);
   // fewer workgroups: the implicit GEMM's split tiles fill the chip better (the 512-channel form holds 122 KB of LDS, one
   // workgroup per CU: 256 of them are one full round)
   // ... and many more (B = 64 eval batches: 2048): every workgroup streams the full weight matrix of its filter group, so the
   // weight traffic grows with the workgroup count and the implicit GEMM's larger tiles win (50 eval forwards of B = 64 in
   // bf16: 105.6 ms with the implicit GEMM, 114.5 ms with this kernel)
-  return wgs >= (k.id == 4 ? 256 : 384) && wgs <= 1024;
+  // (round 6: the lower limit was 384 for the 64 / 128 / 256-channel forms; at 8 images per launch -- train_deep_fake's swap
+  // mode, 256 workgroups each -- the implicit GEMM's split tiles are the slower choice too: 8.09 -> 7.43 ms per combined
+  // swap-mode batch with this limit alone, profiles/r06_plan_mask_8_image_launches.txt)
+  // (the 512-channel form, a whole 8 x 8 image x 32 filters per workgroup: from 128 -- layer4 at 8 images; 7.68 -> 7.43)
+  return wgs >= (k.id == 4 ? 128 : 256) && wgs <= 1024;
 }
 
 void conv_pres_plan(ConvParams& p) {

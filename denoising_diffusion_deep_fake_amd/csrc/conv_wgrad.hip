@@ -583,7 +583,7 @@ int wgrad_plan(WgradParams& p, int dtype) {
   // (round 5 sweep, profiles/README.md: 232 ... 1856): the launches are latency-bound, not MFMA-bound, and the stream is as
   // long as the chain in the backward window -- 1152 is 1.2 % faster per step than 928, 640 1.4 % slower, 1856 1.8 % slower
   // (two networks in one launch share the target: half the slabs per net)
-  const long target = (target_env > 0 ? target_env : (dtype == D3F_BF16 ? 1152 : 928)) / nets_of(p.plan_nets);
+  const long target = (target_env > 0 ? target_env : (dtype == D3F_BF16 ? 1152 : 928)) / plan_nets_for(p.plan_nets, 16);
   long splits = (target + base - 1) / base;
   const long max_splits = (total_chunks + 3) / 4;  // keep >= 4 chunks per slab
   if (splits > max_splits) splits = max_splits;

@@ -563,7 +563,7 @@ void wgrad_patch_grid(const WgradParams& p, int variant, int* gx, int* gy) {
   // the fp32-MFMA kernels: 2 per CU (round 5 sweep 384 / 448 / 512 / 576 / 640 / 768 / 1024 workgroups: 7.85 / 7.81 / 7.80 /
   // 7.94 / 7.91 / 7.875 / 7.91 ms per fp32 step; rounds 1-4 ran 768)
   static const int gall = prof_knob("D3F_WGRAD_PATCH_WGS") ? atoi(prof_knob("D3F_WGRAD_PATCH_WGS")) : 512;  // sweep knob
-  int g = (variant == 7 ? g7 : gall) / nets_of(p.plan_nets) / slices;  // (two networks in one launch share the count)
+  int g = (variant == 7 ? g7 : gall) / plan_nets_for(p.plan_nets, 32) / slices;  // (two networks in one launch share the count)
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   *gx = g;

@@ -48,7 +48,7 @@ bool conv_winograd_fits(const ConvParams& p, int dtype) {
 bool conv_winograd_applies(const ConvParams& p, int dtype) {
   static const bool off = getenv("D3F_NO_WINOGRAD") != nullptr;  // debugging knob: the implicit GEMM instead
   if (off || !conv_winograd_fits(p, dtype)) return false;
-  const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64) * nets_of(p.plan_nets);
+  const long wgs = (long)p.B * (p.Ho / 16) * (p.Wo / 16) * (p.Cout / 64) * plan_nets_for(p.plan_nets, 8);
   // one workgroup per CU or more, and few enough chunks that the fixed cost per workgroup is what the tile form pays for
   // (128 channels on 128 workgroups: 44.9 us against the implicit GEMM's 45)
   return wgs >= 256;

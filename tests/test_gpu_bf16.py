@@ -36,9 +36,11 @@ CASES = [
     (1, 12, 128, 32, 0, 16, 3, 1, 1, False),      # ... 16 of the 32 filter columns real
     (3, 4, 64, 32, 0, 24, 3, 1, 1, False),        # ... a ragged filter count, one tile row per image
     (12, 64, 64, 64, 0, 64, 3, 1, 1, False),      # conv_pres_kernel<64, 64, 2, 2, 1, 2>: patch-resident layer1 form (384 workgroups), forward + data gradient
+    (8, 64, 64, 64, 0, 64, 3, 1, 1, False),       # ... at 8 images (train_deep_fake's per-net batch): 256 workgroups, the lower limit of the plan's rule
     (12, 32, 32, 128, 0, 128, 3, 1, 1, False),    # conv_pres_kernel<128, 32, 4, 1, 1, 1>: layer2 form, 4 filter groups per tile
     (12, 16, 16, 256, 0, 256, 3, 1, 1, False),    # conv_pres_kernel<256, 16, 2, 1, 2, 1>: layer3 form, two k-groups summed through LDS
     (16, 8, 8, 512, 0, 512, 3, 1, 1, False),      # conv_pres_kernel<512, 8, 1, 1, 4, 2>: layer4 form, a whole 8 x 8 image per workgroup, four k-groups
+    (8, 8, 8, 512, 0, 512, 3, 1, 1, False),       # ... at 8 images: 128 workgroups, the lower limit of the plan's rule for this form
     (2, 8, 64, 64, 0, 32, 3, 1, 1, False),        # data gradient 32 -> 64 channels: two 32-filter workgroups per tile (grid.y) of the bf16 32-channel patch kernel
     (1, 12, 128, 48, 0, 32, 3, 1, 1, False),      # ... 32 -> 48: the second filter half is half empty
     (2, 8, 64, 16, 0, 3, 3, 1, 1, False),         # head: data gradient through conv_patch_kernel<bf16, 16, 16, false, 8> (dY 3 -> 8 channels, staged as 16)
