@@ -267,7 +267,7 @@ class Unet(nn.Module):
     # -- runtime state that must not be deep-copied / pickled ------------------------------------
     def _init_runtime_state(self):
         self.__dict__["_rt"] = {"flat": None, "flat_grad": None, "flat_bn": None, "flat_nbt": None,
-                                "engines": {}, "table": None, "dirty": True, "grad_sync": None, "params": None,
+                                "engines": {}, "table": None, "gen": 0, "grad_sync": None, "params": None,
                                 "bn_sync": None}
 
     def __deepcopy__(self, memo):
@@ -364,7 +364,7 @@ class Unet(nn.Module):
                     setattr(bn, attr, view)
                 flat_nbt[i] = bn.num_batches_tracked.to(device)
                 bn.num_batches_tracked = flat_nbt[i]
-        rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, grad_views=None, dirty=True,
+        rt.update(flat=flat, flat_bn=flat_bn, flat_nbt=flat_nbt, flat_grad=None, grad_views=None, gen=rt.get("gen", 0) + 1,
                   params=[named[name] for name, _, _ in ptable], verified=True, bn_first=mods[btable[0][0]])
         for p in named.values():
             p.grad = None
@@ -389,7 +389,10 @@ class Unet(nn.Module):
 
     def mark_params_changed(self):
         """call after writing the flat parameter buffer behind autograd's back (fused Adam / EMA)."""
-        self._rt["dirty"] = True
+        # a generation counter, not a flag: several plans (this network's own engines per shape, a UnetPair's engines)
+        # hold packed copies of these weights and each compares its own stamp -- a flag cleared by whichever plan packed
+        # first would leave the others on stale layouts
+        self._rt["gen"] = self._rt.get("gen", 0) + 1
 
     @property
     def flat_params(self):
@@ -495,15 +498,16 @@ class Unet(nn.Module):
         rt = self._rt
         # `p.data = view` keeps every parameter's OWN version counter, so in-place updates by
         # torch optimizers / load_state_dict show up on the parameters, not on the flat buffer
-        ver = sum(p._version for p in rt["params"]) + rt["flat"]._version
-        if rt["dirty"]:
-            for pool in rt["engines"].values():
-                for e in pool:
-                    e.packed_version = None
-            rt["dirty"] = False
+        ver = self._weights_version()
         if eng.packed_version != ver:
             check(_lib.lib().d3f_unet_pack_weights(eng.h, ptr(rt["flat"]), ptr(eng.workspace), stream_ptr()))
             eng.packed_version = ver
+
+    def _weights_version(self):
+        """stamp of the current parameter values: torch's version counters (in-place torch updates, load_state_dict) and the
+        generation that mark_params_changed() bumps for raw-pointer updates (fused Adam, EMA lerp, re-homed buffers)"""
+        rt = self._rt
+        return (sum(p._version for p in rt["params"]) + rt["flat"]._version, rt.get("gen", 0))
 
     def _run_forward(self, eng, x, training):
         rt = self._rt
@@ -786,19 +790,7 @@ class UnetPair:
         return eng
 
     def _pack_if_needed(self, eng):
-        vers = []
-        for net in self.nets:
-            rt = net._rt
-            vers.append(sum(p._version for p in rt["params"]) + rt["flat"]._version)
-            if rt["dirty"]:  # (the networks' own single plans are stale too; the flag is theirs to clear)
-                for pool in rt["engines"].values():
-                    for e in pool:
-                        e.packed_version = None
-                rt["dirty"] = False
-                for pool in self._engines.values():
-                    for e in pool:
-                        e.packed_version = None
-        ver = tuple(vers)
+        ver = (self.nets[0]._weights_version(), self.nets[1]._weights_version())
         if eng.packed_version != ver:
             a, b = self.nets
             check(_lib.lib().d3f_unet_pair_pack_weights(eng.h, ptr2(a._rt["flat"], b._rt["flat"]), ptr(eng.workspace),

@@ -77,6 +77,39 @@ def test_pair_pass_is_bitwise_each_network_alone_on_the_pair_plan(dtype, shape):
         assert torch.isfinite(nets[0](xs[0])).all()
 
 
+def test_pair_sees_parameter_updates_even_if_each_network_ran_alone_in_between():
+    """The pair's engines hold their own packed copy of both networks' weights.  Sequence of a training loop with a preview
+    callback: pair pass -> both Adam steps (raw-pointer updates of the flat buffers) -> EACH network run alone (its own plan
+    re-packs and is up to date) -> pair pass.  The second pair pass must compute on the UPDATED weights: bit for bit the
+    values of twins that went through the same updates alone (a cleared 'dirty' flag would leave the pair one update behind)."""
+    from denoising_diffusion_deep_fake_amd import UnetPair
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    from denoising_diffusion_deep_fake_amd.optim import FusedAdam
+    nets = _two_nets("f32")
+    twins = [copy.deepcopy(n).cuda().train().set_plan_nets(2) for n in nets]
+    opts = [FusedAdam(n.parameters(), lr=0.01, betas=(0.5, 0.999), module=n) for n in nets + twins]
+    xs = [synthetic_face_crops(2, 64, seed=30 + i, device="cuda") for i in range(2)]
+    tgts = [synthetic_face_crops(2, 64, seed=40 + i, device="cuda") for i in range(2)]
+    pair = UnetPair(*nets)
+    first, _ = _pass(pair, xs, tgts)
+    for i in range(2):
+        _pass(lambda x, i=i: (twins[i](x),), [xs[i]], [tgts[i]])
+    for o in opts:
+        o.step()
+    with torch.no_grad():  # each network alone, on its own plan (a preview / validation forward between two batches)
+        alone_now = [nets[i](xs[i]) for i in range(2)]
+    for n in nets + twins:
+        for p in n.parameters():
+            p.grad = None
+    second, _ = _pass(pair, xs, tgts)
+    for i in range(2):
+        (want,), _ = _pass(lambda x, i=i: (twins[i](x),), [xs[i]], [tgts[i]])
+        assert torch.equal(second[i], want), (i, rel_l2(second[i], want))
+        assert not torch.equal(second[i], first[i])                      # the update moved the prediction
+        assert rel_l2(second[i], alone_now[i]) < 1e-1                     # ... to where the network itself is now
+        assert torch.equal(nets[i].flat_grads, twins[i].flat_grads)
+
+
 def test_pair_against_the_networks_own_single_plans_within_rounding():
     """the 8-image plan of a network alone picks other tiles (k-split 32x32 instead of 64x64 / 128x64, no Winograd): same
     mathematics, another summation order -- the pair must agree with it to fp32 rounding (forward) and to the mask-flip
