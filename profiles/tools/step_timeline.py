@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One training step as seen by rocprofv3's kernel trace: where the two streams of the backward pass are busy / idle.
-   python3 profiles/tools/step_timeline.py <trace_kernel_trace.csv> [step index from the end, default 2]
+   python3 profiles/tools/step_timeline.py <trace_kernel_trace.csv> [step index from the end, default: the step of median span among the last six]
 Step boundaries = launches of adam_kernel.  Prints, for one steady-state step: forward / backward windows, busy time per
 stream, the idle intervals of the weight-gradient (side) stream inside the backward window, and the overhang (side
 stream still running after the main chain's last backward kernel)."""
@@ -12,11 +12,16 @@ def short(n):
     return n.replace("void d3f::", "").replace("d3f::", "").split("(")[0].split("<")[0]
 
 
-def main(path, back=2):
+def main(path, back=None):
     rows = list(csv.DictReader(open(path)))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", r.get("Queue_Id")), short(r["Kernel_Name"]))
                  for r in rows))
     adam = [i for i, e in enumerate(ev) if e[3] == "adam_kernel"]
+    if back is None:
+        # the step of MEDIAN span among the last six (a host hiccup under the tracer -- one 92 ms "step" in the round-6
+        # trace -- says nothing about the schedule)
+        cand = [(ev[adam[-k]][1] - ev[adam[-k - 1]][1], k) for k in range(1, min(7, len(adam)))]
+        back = sorted(cand)[len(cand) // 2][1]
     a0, a1 = adam[-back - 1], adam[-back]
     step = ev[a0 + 1:a1 + 1]
     t0 = ev[a0][1]
@@ -62,4 +67,4 @@ def main(path, back=2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
