@@ -626,6 +626,16 @@ def dp_selftest(args):
             torch.cuda.synchronize()
             times[b].append(1e3 * (time.perf_counter() - t0) / args.steps)
             log(f"dp-selftest round {r} {str(b) + ' buckets + RCCL' if b else 'plain'}: {times[b][-1]:.3f} ms/step")
+    # the exposed-exchange clock of `bench.py --gpus N` (HIP events around reducer.wait()) on the real RCCL backend: with one
+    # rank nothing moves, so this is the floor of config.exposed_allreduce_ms -- what the two event records and the
+    # stream-order waits themselves cost
+    mode(2)
+    red.timing = True
+    for i in range(5):
+        step(i)
+    red.timing = False
+    exposed, nwaits = red.exposed_ms()
+
     def label(b):
         return "plain" if b is None else f"buckets{b}" if isinstance(b, int) else "buckets2_by_segments"
     plain, buck = min(times[None]), min(times[4])
@@ -638,6 +648,7 @@ def dp_selftest(args):
            "dp_tax_by_buckets": {label(b): round(min(times[b]) / plain - 1.0, 4) for b in variants[1:]},
            "all_rounds_ms": {label(b): [round(t, 3) for t in times[b]] for b in variants},
            "bucket_mb": [round(4e-6 * (e - b), 1) for b, e in segs],
+           "exposed_allreduce_ms_floor_single_rank": None if exposed is None else round(exposed, 4), "exposed_waits": nwaits,
            "gradients_bit_identical_to_plain": identical, "final_loss": round(float(loss.item()), 5),
            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("D3F_")}}
     print(json.dumps(res), flush=True)
