@@ -776,6 +776,19 @@ class UnetPair:
         self._engines = {}
         self.last_engine = None
 
+    # plans and workspaces are runtime state (C handles): a copy / pickle of whatever holds the pair starts without them
+    def __deepcopy__(self, memo):
+        import copy
+        return UnetPair(copy.deepcopy(self.nets[0], memo), copy.deepcopy(self.nets[1], memo))
+
+    def __getstate__(self):
+        return {"nets": self.nets}
+
+    def __setstate__(self, st):
+        self.nets = st["nets"]
+        self._engines = {}
+        self.last_engine = None
+
     def _engine(self, B, H, W, device):
         a = self.nets[0]
         key = (B, H, W, a.compute_dtype, device.index)

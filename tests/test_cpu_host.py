@@ -330,3 +330,35 @@ def test_fused_adam_host_side_contracts():
     assert not o.overlap_tail
     (o,), _ = LitModule(**dict(hp, optimizer_overlap_tail=True)).configure_optimizers()
     assert o.overlap_tail
+
+
+def test_unet_pair_host_protocol():
+    """UnetPair (the two nets of train_deep_fake's denoise mode as one set of launches, d3f/train_deep_fake/lit_module.py:142-181)
+    without a GPU: constructor errors, and that copying / pickling whatever holds a pair never duplicates its plans (C
+    handles) -- a copy starts without engines and is bound to the COPIED networks."""
+    import copy
+    import pickle
+
+    import pytest
+    from denoising_diffusion_deep_fake_amd import D3FError, Unet, UnetPair
+    a, b = Unet("resnet18", None, 3, 3, None), Unet("resnet18", None, 3, 3, None)
+    with pytest.raises(TypeError):
+        UnetPair(a, a)
+    with pytest.raises(TypeError):
+        UnetPair(a, object())
+    with pytest.raises(ValueError):
+        UnetPair(a, Unet("resnet34", None, 3, 3, None))
+    with pytest.raises(ValueError):
+        UnetPair(a, Unet("resnet18", None, 3, 3, None, compute_dtype="bf16"))
+    pair = UnetPair(a, b)
+    holder = copy.deepcopy({"pair": pair, "a": a, "b": b})
+    assert holder["pair"].nets == (holder["a"], holder["b"]) and holder["pair"].nets[0] is not a
+    assert holder["pair"]._engines == {} and holder["pair"].last_engine is None
+    again = pickle.loads(pickle.dumps(pair))
+    assert again._engines == {} and len(again.nets) == 2
+    import torch
+    with pytest.raises(D3FError):
+        pair(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))   # CPU tensors: there is no fallback
+    with pytest.raises(ValueError):
+        a.set_plan_nets(3)
+    assert a.set_plan_nets(2) is a and a.plan_nets == 2 and copy.deepcopy(a).plan_nets == 2
