@@ -199,6 +199,17 @@ def test_bench_contract_two_ranks(tmp_path):
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
     assert res["value"] > 0 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
     assert "roofline" in res and "cpu_baseline" not in res and "alt_f32x3" not in res   # N = 1 extras only
+    # bf16 compute: the run also measures the wire format (fp32 / bf16 buckets) -- four candidates, one winner, replicas equal
+    cmd = cmd[:-4] + ["--batch", "4", "--size", "64", "--dtype", "bf16", "--dp-autotune-steps", "1", "--no-kernel-events"]
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    table = res["config"]["dp_autotune"]
+    assert [(t["buckets"], t["grad_compress"]) for t in table] == [(2, "none"), (4, "none"), (2, "bf16"), (4, "bf16")]
+    best = min(table, key=lambda t: t["ms_per_step_max_over_ranks"])
+    assert (res["config"]["dp_buckets"], res["config"]["dp_grad_compress"]) == (best["buckets"], best["grad_compress"])
+    assert res["dtype"] == "bf16" and res["config"]["replicas_bit_identical"] is True
 
 
 def test_bench_self_launch_two_ranks():
