@@ -552,6 +552,13 @@ def extra_workload(args):
                        "conv_gflop_per_step": round(flops_per_step / 1e9, 2)}
     if args.workload == "sample50":
         res.update(extra)
+    if args.workload == "deepfake" and not swap and fused and args.dtype == "f32" and args.size == 256:
+        # HBM bytes per launch of the contraction kernels of the FUSED step (every launch carries both networks), from the
+        # builder's PMC passes over this command -- attached by source digest like the headline's figure
+        traffic, tsrc = pmc_from_file("traffic.json", lambda d: d.get("hbm_bytes_per_launch"), args, tag="deepfake_")
+        res["roofline"]["traffic"] = traffic
+        if tsrc is not None:
+            res["roofline"]["traffic_source"] = tsrc
     print(json.dumps(res), flush=True)
     if args.workload == "sample50" and not extra["replay_equals_eager_bitwise"]:
         raise SystemExit("sample50: hipGraph replay differs from the eager loop")
@@ -678,13 +685,14 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def pmc_from_file(name, key, args):
+def pmc_from_file(name, key, args, tag=None):
     """PMC counters cannot be read from inside this process.  Figures collected by the builder with rocprofv3 (separate
     --pmc passes, gfx950 corrections; profiles/tools/collect_*.sh) are attached WITH their provenance, and only for the
     configuration they were collected on -- they are not measurements of this run."""
     # the newest round's file first (profiles/rNN_<name>); bf16 / 128 / 448 have their own files
-    tag = {("f32", 256, 16): "", ("bf16", 256, 16): "bf16_", ("f32", 128, 16): "128_", ("f32", 448, 14): "448_"}.get(
-        (args.dtype, args.size, args.batch))
+    if tag is None:
+        tag = {("f32", 256, 16): "", ("bf16", 256, 16): "bf16_", ("f32", 128, 16): "128_", ("f32", 448, 14): "448_"}.get(
+            (args.dtype, args.size, args.batch))
     if tag is None:
         return None, None
     path = None

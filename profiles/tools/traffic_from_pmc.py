@@ -32,9 +32,13 @@ def load(counter_dir, counter):
     return rows
 
 
+BLENDS_PER_STEP = 1  # (2: the fused two-network step of `--workload deepfake` blends noise into both batches per step)
+
+
 def steps_of(rows):
-    """list of steps, each a list of rows, cut at noise_blend_kernel; first partial and last open step dropped"""
-    cuts = [i for i, r in enumerate(rows) if "noise_blend_kernel" in r["Kernel_Name"]]
+    """list of steps, each a list of rows, cut at (every BLENDS_PER_STEP-th) noise_blend_kernel; first partial and last
+    open step dropped"""
+    cuts = [i for i, r in enumerate(rows) if "noise_blend_kernel" in r["Kernel_Name"]][::BLENDS_PER_STEP]
     return [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
 
 
@@ -95,4 +99,6 @@ def main(out_dir, traffic_json, kernels_json, head, date, bench_args=""):
 
 
 if __name__ == "__main__":
+    import os
+    BLENDS_PER_STEP = int(os.environ.get("BLENDS_PER_STEP", "1"))
     main(*sys.argv[1:7])
