@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--pair-fused", default="auto", choices=["auto", "on", "off"],
                     help="--workload deepfake, denoise mode: the two nets' steps as ONE set of launches (trainer.optimizer_steps "
                          "takes the fused route when the module offers it); off = Lightning's one-after-the-other loop")
+    ap.add_argument("--pair-batch", type=int, default=8,
+                    help="--workload deepfake: images per domain and step (BASELINE configs[3]: 8; the authors' "
+                         "denoise_config.yml / swap_config.yml: 14 at --size 448)")
     ap.add_argument("--pair-plan", default="off", choices=["on", "off"],
                     help="--workload deepfake: every network plans its kernels as for a UnetPair (hparam pair_plan: the "
                          "tile / split-K / slab choices of a 16-image batch on 8-image launches) -- the A/B of the plan "
@@ -455,7 +458,7 @@ def extra_workload(args):
         return
     if args.workload == "deepfake":
         from denoising_diffusion_deep_fake_amd.train_deep_fake.lit_module import LitModule
-        bs = 8
+        bs = args.pair_batch
         swap = args.mode == "swap"
         # hyper-parameters of denoise_config.yml / swap_config.yml (lambda 3 / 8, ema_beta 0.9999, ema_update_every 1)
         lit = LitModule(mode=args.mode, batch_size=bs, learning_rate=0.01, adam_b1=0.5, adam_b2=0.999, max_epochs=50,
