@@ -403,8 +403,18 @@ def extra_workload(args):
     if args.workload == "fit":
         return fit_workload_deepfake(args) if args.fit_module == "deepfake" else fit_workload(args)
     from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    world, rank, local = 1, 0, 0
+    if args.workload == "deepfake" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # data parallel (one process per GPU, launched as the headline is): each rank its own shard of both domains and its
+        # own noise stream, both nets' gradients all-reduced bucket by bucket from inside the ONE backward pass of the pair
+        from denoising_diffusion_deep_fake_amd.distributed import init_process_group
+        world, rank, local = init_process_group(timeout_s=args.dist_timeout)
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if os.environ.get("D3F_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (gloo)
+            local = int(os.environ["D3F_FORCE_DEVICE"])
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
     torch.manual_seed(0)
     if args.workload == "predict":
         # single-frame inference: uint8 BGR frame -> uint8 BGR frame, B=1, at the
@@ -468,13 +478,21 @@ def extra_workload(args):
                         ema_beta=0.9999, ema_update_every=1, augment=False, pair_plan=args.pair_plan == "on",
                         pair_fused={"auto": None, "on": True, "off": False}[args.pair_fused]).to(dev).train()
         opts, _ = lit.configure_optimizers()
+        if world > 1:
+            import torch.distributed as dist
+            from denoising_diffusion_deep_fake_amd.distributed import DataParallel
+            for opt in opts:  # rank 0's parameters to everyone; each net its own reducer (trainer.Trainer.fit does the same)
+                DataParallel(opt.module, opt, buckets=args.dp_buckets or 2,
+                             grad_compress=None if args.dp_compress in (None, "none") else args.dp_compress)
+            dist.barrier()
+            torch.manual_seed(1000 + rank)
         if swap:
             # steady state of the 200-epoch phase: past ema_pytorch's update_after_step = 100 warm-up copies, every
             # update() is the lerp (one launch over the flat parameters + one over the BatchNorm statistics per net)
             for ema in (lit.ema_model_a, lit.ema_model_b):
                 for _ in range(ema.update_after_step + 2):
                     ema.update()
-        batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i, device=dev), "index": None}
+        batch = {k: {"image": synthetic_face_crops(bs, args.size, seed=7 + i + 97 * rank, device=dev), "index": None}
                  for i, k in enumerate("ab")}
         from denoising_diffusion_deep_fake_amd.trainer import optimizer_steps
         opt_params = [[p for g in o.param_groups for p in g["params"]] for o in opts]
@@ -534,21 +552,43 @@ def extra_workload(args):
                                      "denoise step replayed from a hipGraph")
         flops_per_step = 50 * net.conv_flops(64, args.size, args.size, dev)[0]
         extra = {"ms_per_step_eager": round(eager_ms, 3), "replay_equals_eager_bitwise": bitwise}
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         out = step(i)
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
+    if world > 1:  # the job's time is its slowest rank's; the replicas of BOTH nets must agree bit for bit afterwards
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        same = True
+        for net in (lit.model_a, lit.model_b):
+            cs = net.flat_params.view(torch.int32).to(torch.int64).sum().reshape(1)
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            same = same and bool((lo == hi).item())
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     res = {"workload": name, "dtype": args.dtype, "image_size": args.size, "steps": args.steps,
            "ms_per_step": round(1e3 * dt / args.steps, 3),
-           "images_per_sec": round(images_per_step * args.steps / dt, 2), "last": float(out.item())}
+           "images_per_sec": round(images_per_step * world * args.steps / dt, 2), "last": float(out.item())}
+    if world > 1:
+        res.update(n_gpus=world, scaling="weak", backend=dist.get_backend(), replicas_bit_identical=same,
+                   dp_buckets=args.dp_buckets or 2)
     # whole-workload roofline: algorithmic conv FLOPs (2 x MACs of the ORIGINAL convolutions, SURVEY.md 8d -- Winograd /
     # folded / class-form kernels are credited the direct count) over the wall time of the timed steps, against the
     # dense MFMA peak of the arithmetic type; everything that is not a contraction (BatchNorm, loss, Adam) is inside `dt`
-    tf = flops_per_step * args.steps / dt / 1e12
+    tf = flops_per_step * args.steps / dt / 1e12   # per GPU (weak scaling: every rank steps its own batch)
     res["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                        "frac": round(tf / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                        "basis": "whole timed region (all kernels), conv FLOPs counted as the direct convolution's",
@@ -563,6 +603,10 @@ def extra_workload(args):
         if tsrc is not None:
             res["roofline"]["traffic_source"] = tsrc
     print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+        if not same:
+            raise SystemExit("the replicas' parameters differ after the run: the gradient exchange is broken")
     if args.workload == "sample50" and not extra["replay_equals_eager_bitwise"]:
         raise SystemExit("sample50: hipGraph replay differs from the eager loop")
 
@@ -723,6 +767,8 @@ def pmc_from_file(name, key, args, tag=None):
 
 def main():
     args = parse()
+    if args.workload == "deepfake" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # (the paired-domain step data parallel: BASELINE configs[3] "on 8 x MI355X")
     if args.workload != "denoiser":
         return extra_workload(args)
     if args.dp_selftest:

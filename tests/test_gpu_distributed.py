@@ -447,3 +447,24 @@ def test_pair_fused_step_under_data_parallel_two_ranks():
     _spawn_with_deadline(_pair_dp_worker, (world, _free_port(), ret), world, seconds=240)
     for r in range(world):
         assert all(ret[r].values()), ret[r]
+
+
+def test_bench_deepfake_workload_two_ranks():
+    """`bench.py --workload deepfake --gpus 2` (BASELINE configs[3] is quoted "on 8 x MI355X"): the paired-domain step data
+    parallel, self-launched like the headline, rehearsed with two ranks on the one GPU over gloo -- the fused two-network
+    route under both nets' reducers, whole-job rate from the slowest rank, and BOTH nets' replicas bit-identical afterwards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(D3F_FORCE_DEVICE="0", D3F_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "deepfake", "--gpus", "2", "--steps", "3", "--warmup",
+           "1", "--pair-batch", "2", "--size", "64", "--dist-timeout", "120"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["replicas_bit_identical"] is True and res["scaling"] == "weak"
+    assert "ONE set of launches" in res["workload"] and res["images_per_sec"] > 0 and res["dp_buckets"] == 2
