@@ -723,8 +723,10 @@ def test_denoise_mode_nets_on_two_streams_equal_the_sequential_loop(tmp_path):
 
     def run(concurrent):
         torch.manual_seed(11)
+        # (pair_fused off: the comparison partner is Lightning's one-after-the-other loop on the nets' own plans; the fused
+        # two-network route of round 6 has its own tests, tests/test_gpu_pair.py)
         lit = LitModule(**dict(HP_FAKE, synthetic_length=8, concurrent_optimizers=concurrent, augment=True,
-                               default_root_dir=str(tmp_path)))
+                               pair_fused=False, default_root_dir=str(tmp_path)))
         torch.manual_seed(12)
         tr = Trainer(max_epochs=1, default_root_dir=tmp_path, enable_checkpointing=False).fit(lit)
         torch.cuda.synchronize()
