@@ -207,8 +207,9 @@ def test_bench_contract_two_ranks(tmp_path):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     table = res["config"]["dp_autotune"]
     assert [(t["buckets"], t["grad_compress"]) for t in table] == [(2, "none"), (4, "none"), (2, "bf16"), (4, "bf16")]
-    best = min(table, key=lambda t: t["ms_per_step_max_over_ranks"])
-    assert (res["config"]["dp_buckets"], res["config"]["dp_grad_compress"]) == (best["buckets"], best["grad_compress"])
+    fastest = min(t["ms_per_step_max_over_ranks"] for t in table)
+    assert (res["config"]["dp_buckets"], res["config"]["dp_grad_compress"]) in [
+        (t["buckets"], t["grad_compress"]) for t in table if t["ms_per_step_max_over_ranks"] == fastest]
     assert res["dtype"] == "bf16" and res["config"]["replicas_bit_identical"] is True
 
 
@@ -340,8 +341,9 @@ def test_bench_self_launch_four_ranks_replicas_identical():
     table = cfg["dp_autotune"]
     assert [(t["buckets"], t["grad_compress"]) for t in table] == [(2, "none"), (4, "none")]
     assert all(t["ms_per_step_max_over_ranks"] > 0 for t in table)
-    best = min(table, key=lambda t: t["ms_per_step_max_over_ranks"])
-    assert cfg["dp_buckets"] == best["buckets"] and cfg["dp_grad_compress"] == "none"
+    fastest = min(t["ms_per_step_max_over_ranks"] for t in table)   # (rounded to us in the table: a tie names several)
+    assert cfg["dp_buckets"] in [t["buckets"] for t in table if t["ms_per_step_max_over_ranks"] == fastest]
+    assert cfg["dp_grad_compress"] == "none"
     assert cfg["exposed_allreduce_ms"] is not None and cfg["replicas_bit_identical"] is True
     assert res["value"] > 0 and res["scaling"] == "weak"
 
