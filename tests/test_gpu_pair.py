@@ -77,6 +77,34 @@ def test_pair_pass_is_bitwise_each_network_alone_on_the_pair_plan(dtype, shape):
         assert torch.isfinite(nets[0](xs[0])).all()
 
 
+@pytest.mark.parametrize("dtype,shape", [("f32", (2, 64, 96)), ("bf16", (2, 64, 64)), ("f32", (8, 128, 128))],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_pair_on_a_poisoned_workspace(monkeypatch, dtype, shape):
+    """Both copies of the pair's workspace filled with NaN bit patterns before the first call (D3F_POISON_WORKSPACE): everything
+    network 1 reads from ITS copy -- packed-weight padding, statistics rows, coefficient arrays, split-K and gradient slabs,
+    the zeroed parts of stride-2 gradients -- must have been written by a launch that carried network 1; a kernel that
+    initialised only network 0's copy shows up as NaN, one that read network 0's copy as a mismatch with the twin."""
+    from denoising_diffusion_deep_fake_amd import UnetPair
+    from denoising_diffusion_deep_fake_amd.dataset import synthetic_face_crops
+    monkeypatch.setenv("D3F_POISON_WORKSPACE", "1")
+    B, H, W = shape
+    nets = _two_nets(dtype)
+    twins = [copy.deepcopy(n).cuda().train().set_plan_nets(2) for n in nets]
+    xs = [synthetic_face_crops(B, (H, W), seed=60 + i, device="cuda") for i in range(2)]
+    tgts = [synthetic_face_crops(B, (H, W), seed=70 + i, device="cuda") for i in range(2)]
+    pair = UnetPair(*nets)
+    for _ in range(2):  # second pass: re-uses the arenas after a backward
+        for n in nets + twins:
+            for p in n.parameters():
+                p.grad = None
+        preds, _ = _pass(pair, xs, tgts)
+        for i in range(2):
+            (alone,), _ = _pass(lambda x, i=i: (twins[i](x),), [xs[i]], [tgts[i]])
+            assert torch.isfinite(preds[i]).all() and torch.isfinite(nets[i].flat_grads).all(), i
+            assert torch.equal(preds[i], alone) and torch.equal(nets[i].flat_grads, twins[i].flat_grads), i
+    assert pair.last_engine.workspace.numel() == 2 * pair.last_engine.net_stride
+
+
 def test_pair_sees_parameter_updates_even_if_each_network_ran_alone_in_between():
     """The pair's engines hold their own packed copy of both networks' weights.  Sequence of a training loop with a preview
     callback: pair pass -> both Adam steps (raw-pointer updates of the flat buffers) -> EACH network run alone (its own plan
